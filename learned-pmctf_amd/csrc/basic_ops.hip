@@ -1,0 +1,254 @@
+// basic_ops.hip — bandwidth-bound primitives of the pMCTF encode path (vector ALU,
+// coalesced NHWC / planar accesses).  Each kernel restates one torch functional op of
+// the reference in PM-F32 arithmetic (same operation order as oracle/c/pm_ops.c).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pm_device_math.h"
+#include "../../include/pmctf_hip.h"
+
+namespace {
+
+inline int launch_ok() { return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH; }
+inline unsigned nblocks(long n, int bs = 256) {
+    long b = (n + bs - 1) / bs;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------------------------
+// direct conv for Cin <= 4: one thread per output element, cout fastest (NHWC store).
+// acc = bias; for ky: for kx: for ci: fmaf   (single 16-channel chunk of the spec order)
+__global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                     const float *__restrict__ bias, const float *res1, const float *res2,
+                                     float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int S,
+                                     int ph, int pw, int Ho, int Wo, int act, float slope) {
+    extern __shared__ float wl[];  // [tap][ci][co]
+    const int taps = KH * KW;
+    for (int i = threadIdx.x; i < Cout * Cin * taps; i += blockDim.x) {
+        const int co = i / (Cin * taps), r = i - co * Cin * taps;
+        const int ci = r / taps, t = r - ci * taps;
+        wl[(t * Cin + ci) * Cout + co] = w[i];
+    }
+    __syncthreads();
+    const long total = (long)N * Ho * Wo * Cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        long p = idx / Cout;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float acc = bias ? bias[co] : 0.0f;
+        for (int ky = 0; ky < KH; ++ky) {
+            const int iy = oy * S + ky - ph;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < KW; ++kx) {
+                const int ix = ox * S + kx - pw;
+                if (ix < 0 || ix >= W) continue;
+                const float *xp = x + (((long)n * H + iy) * W + ix) * Cin;
+                const float *wp = wl + ((ky * KW + kx) * Cin) * Cout + co;
+                for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci * Cout], acc);
+            }
+        }
+        float v = pm::apply_act(acc, act, slope);
+        if (res1) v = v + res1[idx];
+        if (res2) v = v + res2[idx];
+        y[idx] = v;
+    }
+}
+
+// depthwise KxK, stride 1, pad K/2; NHWC, channel fastest
+__global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                              float *y, int N, int H, int W, int C, int K) {
+    const int pad = K / 2;
+    const long total = (long)N * H * W * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long p = idx / C;
+        const int ox = (int)(p % W); p /= W;
+        const int oy = (int)(p % H);
+        const int n = (int)(p / H);
+        float acc = bias ? bias[c] : 0.0f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox + kx - pad;
+                if (ix < 0 || ix >= W) continue;
+                acc = __builtin_fmaf(x[(((long)n * H + iy) * W + ix) * C + c], w[(c * K + ky) * K + kx], acc);
+            }
+        }
+        y[idx] = acc;
+    }
+}
+
+// flow warp: one thread per output pixel, loop over planes
+__global__ void flow_warp_kernel(const float *__restrict__ im, const float *__restrict__ flow,
+                                 const float *__restrict__ lin_x, const float *__restrict__ lin_y, float *out,
+                                 int N, int C, int H, int W, int flowN, float sign) {
+    const long HW = (long)H * W;
+    const long total = (long)N * HW;
+    const float cx = (float)(W - 1) / 2.0f, cy = (float)(H - 1) / 2.0f;
+    const float mx = (float)(W - 1), my = (float)(H - 1);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / HW);
+        const long p = idx - (long)n * HW;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        const float *f = flow + (flowN == 1 ? 0 : (long)n * 2 * HW);
+        const float fx = sign * f[p], fy = sign * f[HW + p];
+        const float gx = lin_x[x] + fx / cx;
+        const float gy = lin_y[y] + fy / cy;
+        float ix = (gx + 1.0f) * cx;
+        float iy = (gy + 1.0f) * cy;
+        ix = __builtin_fminf(mx, __builtin_fmaxf(ix, 0.0f));
+        iy = __builtin_fminf(my, __builtin_fmaxf(iy, 0.0f));
+        const float xw = __builtin_floorf(ix), yn = __builtin_floorf(iy);
+        const float w = ix - xw, e = 1.0f - w;
+        const float nn = iy - yn, s = 1.0f - nn;
+        const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+        const int x0 = (int)xw, y0 = (int)yn;
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const bool x1ok = x1 <= W - 1, y1ok = y1 <= H - 1;
+        for (int c = 0; c < C; ++c) {
+            const float *pl = im + ((long)n * C + c) * HW;
+            const float v00 = pl[(long)y0 * W + x0];
+            const float v01 = x1ok ? pl[(long)y0 * W + x1] : 0.0f;
+            const float v10 = y1ok ? pl[(long)y1 * W + x0] : 0.0f;
+            const float v11 = (x1ok && y1ok) ? pl[(long)y1 * W + x1] : 0.0f;
+            float r = v00 * nw;
+            r = __builtin_fmaf(v01, ne, r);
+            r = __builtin_fmaf(v10, sw, r);
+            r = __builtin_fmaf(v11, se, r);
+            out[((long)n * C + c) * HW + p] = r;
+        }
+    }
+}
+
+__global__ void avgpool2_kernel(const float *__restrict__ x, float *y, int NC, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)NC * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        long p = idx / Wo;
+        const int oy = (int)(p % Ho);
+        const long nc = p / Ho;
+        const float *r0 = x + (nc * H + 2 * oy) * W + 2 * ox;
+        const float *r1 = r0 + W;
+        float s = r0[0] + r0[1];
+        s = s + r1[0];
+        s = s + r1[1];
+        y[idx] = s / 4.0f;
+    }
+}
+
+__device__ __forceinline__ void up2_coef(int d, int size, int &i0, int &i1, float &l0, float &l1) {
+    float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int a = (int)__builtin_floorf(src);
+    if (a > size - 1) a = size - 1;
+    float lam = src - (float)a;
+    if (lam < 0.0f) lam = 0.0f;
+    if (lam > 1.0f) lam = 1.0f;
+    i0 = a;
+    i1 = a + (a < size - 1 ? 1 : 0);
+    l1 = lam;
+    l0 = 1.0f - lam;
+}
+
+__global__ void bilinear_up2_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float scale) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)NC * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        long p = idx / Wo;
+        const int oy = (int)(p % Ho);
+        const long nc = p / Ho;
+        int x0, x1, y0, y1;
+        float lx0, lx1, ly0, ly1;
+        up2_coef(ox, W, x0, x1, lx0, lx1);
+        up2_coef(oy, H, y0, y1, ly0, ly1);
+        const float *r0 = x + (nc * H + y0) * W, *r1 = x + (nc * H + y1) * W;
+        const float t0 = __builtin_fmaf(r0[x0], lx0, r0[x1] * lx1);
+        const float t1 = __builtin_fmaf(r1[x0], lx0, r1[x1] * lx1);
+        y[idx] = __builtin_fmaf(t0, ly0, t1 * ly1) * scale;
+    }
+}
+
+__global__ void bilinear_down2_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float div) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)NC * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        long p = idx / Wo;
+        const int oy = (int)(p % Ho);
+        const long nc = p / Ho;
+        const float *r0 = x + (nc * H + 2 * oy) * W + 2 * ox;
+        const float *r1 = r0 + W;
+        const float t0 = r0[0] * 0.5f + r0[1] * 0.5f;
+        const float t1 = r1[0] * 0.5f + r1[1] * 0.5f;
+        y[idx] = (t0 * 0.5f + t1 * 0.5f) / div;
+    }
+}
+
+}  // namespace
+
+extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const float *bias, const float *res1,
+                                         const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                         int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                                         void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || KH <= 0 || KW <= 0 ||
+        stride <= 0)
+        return PMCTF_EINVAL;
+    const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
+    const size_t smem = (size_t)Cout * Cin * KH * KW * sizeof(float);
+    if (smem > 64 * 1024) return PMCTF_EINVAL;
+    const long total = (long)N * Ho * Wo * Cout;
+    unsigned g = nblocks(total);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(g), dim3(256), smem, (hipStream_t)stream, x, w, bias, res1, res2, y,
+                       N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo, act, slope);
+    return launch_ok();
+}
+
+extern "C" int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
+                                       int W, int C, int K, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !(K & 1)) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)N * H * W * C);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(dwconv_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C, K);
+    return launch_ok();
+}
+
+extern "C" int pmctf_flow_warp_f32(const float *im, const float *flow, const float *lin_x, const float *lin_y,
+                                   float *out, int N, int C, int H, int W, int flowN, float flow_sign, void *stream) {
+    if (!im || !flow || !lin_x || !lin_y || !out || N <= 0 || C <= 0 || H < 2 || W < 2 || (flowN != 1 && flowN != N))
+        return PMCTF_EINVAL;
+    unsigned g = nblocks((long)N * H * W);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, im, flow, lin_x, lin_y, out, N, C,
+                       H, W, flowN, flow_sign);
+    return launch_ok();
+}
+
+extern "C" int pmctf_avgpool2_f32(const float *x, float *y, int NC, int H, int W, void *stream) {
+    if (!x || !y || NC <= 0 || H < 2 || W < 2) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)NC * (H / 2) * (W / 2));
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W);
+    return launch_ok();
+}
+
+extern "C" int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, int W, float scale, void *stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)NC * H * W * 4);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(bilinear_up2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, scale);
+    return launch_ok();
+}
+
+extern "C" int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H, int W, float div, void *stream) {
+    if (!x || !y || NC <= 0 || H < 2 || W < 2) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)NC * (H / 2) * (W / 2));
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(bilinear_down2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, div);
+    return launch_ok();
+}

@@ -1,0 +1,261 @@
+// conv_mfma.hip — implicit-GEMM convolution on the gfx950 matrix cores, exact f32.
+//
+// Replaces F.conv2d behind the reference's nn.Conv2d layers (pmctf_hip.h lists the
+// call sites).  D[cout x pixel] += A[cout x k] * B[k x pixel] with
+// v_mfma_f32_16x16x4_f32, whose result is bit-for-bit a k-ordered fmaf chain, so the
+// sum order of the PM-F32 spec is reproduced exactly:
+//   acc = bias; for 16-channel chunk cb: for ky: for kx: for ci in chunk: fmaf
+// Workgroup = 4 waves (256 threads) = one TH x TW output tile of one image, all MT
+// 16-row cout tiles of one M-block.  Per chunk the input patch (tile + halo, 16
+// channels) is staged NHWC -> LDS once and shared by the 4 waves; each wave owns
+// NT 16-pixel row segments and keeps MT*NT accumulators (4 VGPRs each).  Weight
+// fragments are pre-packed on the host in lane order and read straight from L2
+// (every workgroup reads the same <=0.5 MB).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "pm_device_math.h"
+#include "../../include/pmctf_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CB = 16;       // channels per chunk
+constexpr int CP = 18;       // LDS pixel stride in words (16 + 2: conflict-free b32 reads, 8-B aligned)
+constexpr int WAVES = 4;
+
+struct ConvArgs {
+    const float *x, *wp, *bp, *res1, *res2;
+    float *y;
+    int N, H, W, Cin, Cout, KH, KW, S, pad_h, pad_w, Ho, Wo;
+    int tiles_x, tiles_y, ncb, act;
+    float slope;
+};
+
+// MT: cout tiles per workgroup, NT: pixel tiles per wave, TW16: 16-pixel segments per tile row.
+template <int MT, int NT, int TW16>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TW = TW16 * 16;
+    constexpr int TH = NT * WAVES / TW16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mb = blockIdx.z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
+    const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
+    const int taps = a.KH * a.KW;
+
+    // accumulators start at the bias: acc = bias[co]
+    f32x4 acc[MT][NT];
+    {
+        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+        }
+    }
+    // per-lane LDS word offset of (pixel lane&15 of segment nt, channel lane>>4)
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int seg = wave * NT + nt;
+        const int r = seg / TW16, c16 = seg - r * TW16;
+        boff[nt] = ((r * a.S) * LW + (c16 * 16 + (lane & 15)) * a.S) * CP + (lane >> 4);
+    }
+    const int E = LH * LW * 4;  // float4 units per chunk
+    const float *wbase = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;
+
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        __syncthreads();  // previous chunk fully consumed
+        for (int e = tid; e < E; e += 256) {
+            const int pix = e >> 2, part = e & 3;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = iy0 + ly, gx = ix0 + lx;
+            const int c = cb * CB + part * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin)
+                v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + c);
+            float2 *dst = (float2 *)(lds + pix * CP + part * 4);
+            dst[0] = make_float2(v.x, v.y);
+            dst[1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        const int crem = a.Cin - cb * CB;
+        const int ksteps = crem >= CB ? 4 : (crem + 3) >> 2;
+        const float *wc = wbase + (size_t)cb * taps * (MT * 256);
+        int tap = 0;
+        for (int ky = 0; ky < a.KH; ++ky) {
+            for (int kx = 0; kx < a.KW; ++kx, ++tap) {
+                f32x4 af[MT];  // af[mt][ks]: A fragment of k-step ks
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = *(const f32x4 *)(wc + (size_t)tap * (MT * 256) + mt * 256);
+                const int toff = (ky * LW + kx) * CP;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < ksteps) {
+                        float bf[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bf[nt] = lds[boff[nt] + toff + ks * 4];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][ks], bf[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: lane holds couts co..co+3 of pixel (lane&15) of each segment
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int seg = wave * NT + nt;
+        const int r = seg / TW16, c16 = seg - r * TW16;
+        const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            if (co >= a.Cout) continue;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (co + i < a.Cout) {
+                        float s = v[i];
+                        if (a.res1) s = s + a.res1[pbase + co + i];
+                        if (a.res2) s = s + a.res2[pbase + co + i];
+                        a.y[pbase + co + i] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
+void choose_mt(int Cout, int &MT, int &MB) {
+    const int tiles = (Cout + 15) / 16;
+    static const int allowed[5] = {1, 2, 4, 7, 8};
+    int best_mt = 8, best_mb = (tiles + 7) / 8, best_cost = 1 << 30;
+    for (int i = 0; i < 5; ++i) {
+        const int mt = allowed[i];
+        const int mb = (tiles + mt - 1) / mt;
+        const int cost = mt * mb * 8 + mb;  // padded MFMA work first, then restaging
+        if (cost < best_cost) { best_cost = cost; best_mt = mt; best_mb = mb; }
+    }
+    MT = best_mt; MB = best_mb;
+}
+
+template <int MT, int NT, int TW16>
+int launch(const ConvArgs &a, int MB, hipStream_t st) {
+    constexpr int TW = TW16 * 16;
+    constexpr int TH = NT * WAVES / TW16;
+    ConvArgs b = a;
+    b.tiles_x = (a.Wo + TW - 1) / TW;
+    b.tiles_y = (a.Ho + TH - 1) / TH;
+    const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
+    const size_t smem = (size_t)LH * LW * CP * sizeof(float);
+    if (smem > 160 * 1024) return PMCTF_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv_mfma_kernel<MT, NT, TW16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
+    return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH;
+}
+
+template <int MT>
+int dispatch_tile(const ConvArgs &a, int MB, hipStream_t st) {
+    // big tile 8x32 (NT=4) when the image is large and stride 1; 8x16 (NT=2) for stride 2 / mid sizes;
+    // 4x16 (NT=1) for small planes so that more than a handful of workgroups exist.
+    const long px = (long)a.Ho * a.Wo * a.N;
+    if (MT < 8 && a.S == 1 && px >= 256L * 256 * 2 && a.KH <= 7) return launch<MT, 4, 2>(a, MB, st);
+    if (px >= 64L * 64 * 4) return launch<MT, 2, 1>(a, MB, st);
+    return launch<MT, 1, 1>(a, MB, st);
+}
+
+}  // namespace
+
+extern "C" int64_t pmctf_conv2d_packed_bias_size(int Cout) {
+    int MT, MB;
+    choose_mt(Cout, MT, MB);
+    return (int64_t)MT * MB * 16;
+}
+
+extern "C" int64_t pmctf_conv2d_packed_size(int Cout, int Cin, int KH, int KW) {
+    int MT, MB;
+    choose_mt(Cout, MT, MB);
+    const int ncb = (Cin + CB - 1) / CB;
+    return (int64_t)MB * ncb * KH * KW * MT * 256;
+}
+
+// layout: [mb][cb][tap][mt][lane][ks]  value = W[co=(mb*MT+mt)*16+(lane&15)][ci=cb*16+ks*4+(lane>>4)][tap]
+extern "C" int pmctf_conv2d_pack_weights(const float *w, const float *bias, int Cout, int Cin, int KH, int KW,
+                                         float *wp, float *bp) {
+    int MT, MB;
+    choose_mt(Cout, MT, MB);
+    const int ncb = (Cin + CB - 1) / CB, taps = KH * KW;
+    for (int mb = 0; mb < MB; ++mb)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int t = 0; t < taps; ++t)
+                for (int mt = 0; mt < MT; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const int co = (mb * MT + mt) * 16 + (lane & 15);
+                            const int ci = cb * CB + ks * 4 + (lane >> 4);
+                            float v = 0.f;
+                            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + t];
+                            wp[(((((size_t)mb * ncb + cb) * taps + t) * MT + mt) * 64 + lane) * 4 + ks] = v;
+                        }
+    for (int i = 0; i < MT * MB * 16; ++i) bp[i] = (bias && i < Cout) ? bias[i] : 0.f;
+    return PMCTF_OK;
+}
+
+extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                     const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                     int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                                     void *stream) {
+    if (!x || !wp || !bp || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
+        KH <= 0 || KW <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0)
+        return PMCTF_EINVAL;
+    ConvArgs a;
+    a.x = x; a.wp = wp; a.bp = bp; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.S = stride;
+    a.pad_h = pad_h; a.pad_w = pad_w;
+    a.Ho = (H + 2 * pad_h - KH) / stride + 1;
+    a.Wo = (W + 2 * pad_w - KW) / stride + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return PMCTF_EINVAL;
+    a.ncb = (Cin + CB - 1) / CB;
+    a.act = act; a.slope = slope;
+    a.tiles_x = a.tiles_y = 0;
+    int MT, MB;
+    choose_mt(Cout, MT, MB);
+    hipStream_t st = (hipStream_t)stream;
+    switch (MT) {
+    case 1: return dispatch_tile<1>(a, MB, st);
+    case 2: return dispatch_tile<2>(a, MB, st);
+    case 4: return dispatch_tile<4>(a, MB, st);
+    case 7: return dispatch_tile<7>(a, MB, st);
+    default: return dispatch_tile<8>(a, MB, st);
+    }
+}

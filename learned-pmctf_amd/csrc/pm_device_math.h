@@ -1,0 +1,88 @@
+// PM-F32 scalar arithmetic on the device: the same operation sequences as the
+// arithmetic spec in DESIGN.md §"PM-F32" (one IEEE binary32 rounding per written
+// operation, explicit fmaf only; build with -ffp-contract=off).
+// Replaces torch.tanh / torch.sigmoid / torch.log of the reference
+// (pMCTF/layers/lifting_1d.py:39,42; pMCTF/layers/long_context.py:24-32;
+//  pMCTF/entropy_models/entropy_models.py:271).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pm {
+
+__device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
+
+// exp(x) = (1+q) * 2^n
+__device__ __forceinline__ float exp_core(float x, int &n) {
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
+    const float nf = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(nf, -0.693145751953125f, x);
+    r = __builtin_fmaf(nf, -1.42860682030941723212e-6f, r);
+    float p = 1.9841270e-4f;
+    p = __builtin_fmaf(p, r, 1.3888889e-3f);
+    p = __builtin_fmaf(p, r, 8.3333333e-3f);
+    p = __builtin_fmaf(p, r, 4.1666667e-2f);
+    p = __builtin_fmaf(p, r, 1.6666667e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    const float r2 = r * r;
+    n = (int)nf;
+    return __builtin_fmaf(p, r2, r);
+}
+
+__device__ __forceinline__ float expf_(float x) {
+    int n;
+    const float q = exp_core(x, n);
+    const float s = u2f((unsigned)(n + 127) << 23);
+    return (q + 1.0f) * s;
+}
+
+__device__ __forceinline__ float tanhf_(float x) {
+    const float a = __builtin_fabsf(x);
+    int n;
+    const float q = exp_core(-2.0f * a, n);
+    float em1;
+    if (n == 0) {
+        em1 = q;
+    } else {
+        const float s = u2f((unsigned)(n + 127) << 23);
+        em1 = (q + 1.0f) * s - 1.0f;
+    }
+    const float t = -em1 / (em1 + 2.0f);
+    return __builtin_copysignf(t, x);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf_(-x)); }
+
+__device__ __forceinline__ float logf_(float x) {
+    const unsigned u = f2u(x);
+    int e = (int)(u >> 23) - 127;
+    float m = u2f((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = 0.2222222222f;
+    p = __builtin_fmaf(p, z, 0.2857142857f);
+    p = __builtin_fmaf(p, z, 0.4f);
+    p = __builtin_fmaf(p, z, 0.6666666667f);
+    const float lm = __builtin_fmaf(p * z, s, 2.0f * s);
+    const float ef = (float)e;
+    const float lo = __builtin_fmaf(ef, 9.0580006145e-6f, lm);
+    return __builtin_fmaf(ef, 0.693138123f, lo);
+}
+
+// activations used in conv epilogues
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+    case ACT_RELU: return v > 0.0f ? v : 0.0f;            // torch.relu: max(v,0); -0 -> 0 numerically equal
+    case ACT_LEAKY: return v > 0.0f ? v : v * slope;      // F.leaky_relu
+    case ACT_TANH: return tanhf_(v);
+    case ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+    }
+}
+
+}  // namespace pm

@@ -1,0 +1,309 @@
+/* ORACLE — test infrastructure only (see pm_math.h header note).
+ *
+ * pm_ops.c: CPU restatement, in specified f32 arithmetic ("PM-F32"), of the
+ * tensor primitives the reference's hot path calls through torch.  Layout is
+ * NCHW contiguous float32, as in the reference.  Every function states the
+ * reference call site it replaces and the exact operation order; the HIP
+ * kernels in learned-pmctf_amd/csrc follow the same order and are compared
+ * bit-for-bit against these in tests/.
+ *
+ * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp -shared -fPIC
+ */
+#include "pm_math.h"
+#include <immintrin.h>
+#include <stdlib.h>
+
+
+/* ---- tiny pthread parallel-for (no OpenMP: libgomp's spinning workers fight with the
+ * thread pools of numpy/torch living in the same test process) ------------------------ */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <unistd.h>
+typedef void (*pm_job_fn)(long job, void *ctx);
+typedef struct { pm_job_fn fn; void *ctx; long n, chunk; atomic_long next; } pm_pf;
+static void *pm_pf_worker(void *p) {
+    pm_pf *pf = (pm_pf *)p;
+    for (;;) {
+        const long b = atomic_fetch_add(&pf->next, pf->chunk);
+        if (b >= pf->n) break;
+        const long e = b + pf->chunk < pf->n ? b + pf->chunk : pf->n;
+        for (long j = b; j < e; ++j) pf->fn(j, pf->ctx);
+    }
+    return NULL;
+}
+static int pm_num_threads(void) {
+    const char *e = getenv("PM_ORACLE_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return (int)n;
+}
+static void pm_parallel_for(long n, long chunk, pm_job_fn fn, void *ctx) {
+    pm_pf pf; pf.fn = fn; pf.ctx = ctx; pf.n = n; pf.chunk = chunk < 1 ? 1 : chunk; atomic_init(&pf.next, 0);
+    int nt = pm_num_threads();
+    if ((long)nt * pf.chunk > n) nt = (int)((n + pf.chunk - 1) / pf.chunk);
+    if (nt <= 1) { pm_pf_worker(&pf); return; }
+    pthread_t th[64];
+    for (int i = 1; i < nt; ++i) pthread_create(&th[i], NULL, pm_pf_worker, &pf);
+    pm_pf_worker(&pf);
+    for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+}
+
+#define PM_CB 16 /* input-channel chunk of the convolution order */
+
+/* ---------------------------------------------------------------------------
+ * conv2d (groups=1, zero padding, square stride).
+ * Replaces nn.Conv2d / F.conv2d at e.g. pMCTF/layers/video/video_net.py:78-90,
+ * pMCTF/layers/lifting_1d.py:30-47, pMCTF/layers/context_fusion_4step.py:12-20,
+ * pMCTF/layers/postprocessing.py:9-44, pMCTF/layers/video/layers.py:22-136.
+ * Order per output element:
+ *   acc = bias[co]
+ *   for cb in chunks of 16 input channels:
+ *     for ky: for kx: for ci in chunk: acc = fmaf(x, w, acc)   (out-of-image taps skipped == +0)
+ * ------------------------------------------------------------------------- */
+#define PM_XB 32 /* output columns kept in registers */
+typedef struct {
+    const float *xp, *w, *bias; float *y;
+    int N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc;
+} pm_conv_ctx;
+
+static void pm_conv_job(long job, void *vctx) {
+    const pm_conv_ctx *c = (const pm_conv_ctx *)vctx;
+    const int Ho = c->Ho, Wo = c->Wo, Cin = c->Cin, Cout = c->Cout, KH = c->KH, KW = c->KW, stride = c->stride;
+    const int Hc = c->Hc, Wc = c->Wc;
+    const float *xp = c->xp, *w = c->w;
+    /* job order: cout fastest, so that consecutive jobs re-read the same few input rows (L2-resident) */
+    const int co = (int)(job % Cout);
+    const int oy = (int)((job / Cout) % Ho);
+    const int n = (int)(job / ((long)Ho * Cout));
+    float *restrict out = c->y + (((long)n * Cout + co) * Ho + oy) * Wo;
+    const float b = c->bias ? c->bias[co] : 0.0f;
+    for (int xb = 0; xb < Wo; xb += PM_XB) {
+        float acc[PM_XB];
+        if (stride == 1) {
+            /* 4 x 8 lanes held in registers; _mm256_fmadd_ps is the same single-rounding fmaf per lane */
+            __m256 a0 = _mm256_set1_ps(b), a1 = a0, a2 = a0, a3 = a0;
+            for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
+                const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        for (int ci = c0; ci < c1; ++ci) {
+                            const __m256 wv = _mm256_set1_ps(w[(((long)co * Cin + ci) * KH + ky) * KW + kx]);
+                            const float *row = xp + (((long)n * Hc + oy + ky) * Cin + ci) * Wc + xb + kx;
+                            a0 = _mm256_fmadd_ps(_mm256_loadu_ps(row), wv, a0);
+                            a1 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 8), wv, a1);
+                            a2 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 16), wv, a2);
+                            a3 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 24), wv, a3);
+                        }
+            }
+            _mm256_storeu_ps(acc, a0); _mm256_storeu_ps(acc + 8, a1);
+            _mm256_storeu_ps(acc + 16, a2); _mm256_storeu_ps(acc + 24, a3);
+        } else {
+            for (int j = 0; j < PM_XB; ++j) acc[j] = b;
+            for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
+                const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        for (int ci = c0; ci < c1; ++ci) {
+                            const float wv = w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+                            const float *restrict row = xp + (((long)n * Hc + (long)oy * stride + ky) * Cin + ci) * Wc +
+                                                        (long)xb * stride + kx;
+                            for (int j = 0; j < PM_XB; ++j) acc[j] = fmaf(row[(long)j * stride], wv, acc[j]);
+                        }
+            }
+        }
+        const int lim = Wo - xb < PM_XB ? Wo - xb : PM_XB;
+        for (int j = 0; j < lim; ++j) out[xb + j] = acc[j];
+    }
+}
+
+void pm_conv2d(const float *restrict x, const float *restrict w, const float *restrict bias, float *restrict y,
+               int N, int Cin, int H, int W, int Cout, int KH, int KW,
+               int stride, int pad_h, int pad_w) {
+    const int Ho = (H + 2 * pad_h - KH) / stride + 1;
+    const int Wo = (W + 2 * pad_w - KW) / stride + 1;
+    /* zero-padded copy of the input: out-of-image taps then contribute fmaf(0, w, acc) == acc,
+     * which is the same value as skipping them */
+    const int Wo_pad = (Wo + PM_XB - 1) / PM_XB * PM_XB;
+    const int Hp = (Ho - 1) * stride + KH;
+    const int Wp = (Wo_pad - 1) * stride + KW;
+    const int Hc = Hp > H + 2 * pad_h ? Hp : H + 2 * pad_h;
+    const int Wc = Wp > W + 2 * pad_w ? Wp : W + 2 * pad_w;
+    float *xp = (float *)calloc((size_t)N * Cin * Hc * Wc, sizeof(float));
+    /* padded copy laid out [n][y][ci][x]: the KH x Cin rows one output row needs are contiguous */
+    for (long r = 0; r < (long)N * Cin * H; ++r) {
+        const long nc = r / H; const int iy = (int)(r % H);
+        const long n = nc / Cin; const int ci = (int)(nc % Cin);
+        memcpy(xp + ((n * Hc + iy + pad_h) * Cin + ci) * Wc + pad_w, x + r * W, (size_t)W * sizeof(float));
+    }
+    pm_conv_ctx c = {xp, w, bias, y, N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc};
+    pm_parallel_for((long)N * Cout * Ho, Cout < 16 ? Cout : 16, pm_conv_job, &c);
+    free(xp);
+}
+
+/* depthwise KxK conv, stride 1, zero pad K/2 (pMCTF/layers/video/layers.py:117-118).
+ * acc = bias[c]; for ky: for kx: acc = fmaf(x, w, acc) */
+void pm_dwconv2d(const float *x, const float *w, const float *bias, float *y,
+                 int N, int C, int H, int W, int K) {
+    const int pad = K / 2;
+    const long total = (long)N * C * H;
+    for (long job = 0; job < total; ++job) {
+        const int oy = (int)(job % H);
+        const int c = (int)((job / H) % C);
+        const int n = (int)(job / ((long)H * C));
+        float *acc = y + (((long)n * C + c) * H + oy) * W;
+        const float b = bias ? bias[c] : 0.0f;
+        for (int ox = 0; ox < W; ++ox) acc[ox] = b;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int off = kx - pad;
+                const int lo = off < 0 ? -off : 0;
+                const int hi = off > 0 ? W - off : W;
+                const float wv = w[((long)c * K + ky) * K + kx];
+                const float *row = x + (((long)n * C + c) * H + iy) * W + off;
+                for (int ox = lo; ox < hi; ++ox) acc[ox] = fmaf(row[ox], wv, acc[ox]);
+            }
+        }
+    }
+}
+
+/* elementwise transcendental maps (see pm_math.h) */
+void pm_tanh_arr(const float *x, float *y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = pm_tanhf(x[i]);
+}
+void pm_sigmoid_arr(const float *x, float *y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = pm_sigmoidf(x[i]);
+}
+void pm_log_arr(const float *x, float *y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = pm_logf(x[i]);
+}
+void pm_exp_arr(const float *x, float *y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = pm_expf(x[i]);
+}
+
+/* ---------------------------------------------------------------------------
+ * flow_warp: pMCTF/layers/video/video_net.py:32-55 (torch_warp) =
+ * grid_sample(bilinear, padding_mode='border', align_corners=True) of the grid
+ * lin + flow/((size-1)/2).  lin_x[W], lin_y[H] are the cached linspace(-1,1,.)
+ * tables of video_net.py:36-40 (an input: torch builds them once per shape).
+ * Per output pixel:
+ *   gx = lin_x[x] + fx / cx            cx = (W-1)/2   (IEEE division)
+ *   ix = (gx + 1) * cx ; ix = min(W-1, max(ix, 0))
+ *   xw = floor(ix); w = ix - xw; e = 1 - w          (same for y: n, s)
+ *   nw = s*e, ne = s*w, sw = n*e, se = n*w
+ *   out = fmaf(v_se,se, fmaf(v_sw,sw, fmaf(v_ne,ne, v_nw*nw)))   (what ATen's CPU grid_sampler
+ *         evaluates, bit for bit, on this image; out-of-range neighbours have weight 0 and add +0)
+ * ------------------------------------------------------------------------- */
+void pm_flow_warp(const float *im, const float *flow, const float *lin_x, const float *lin_y,
+                  float *out, int N, int C, int H, int W, int flowN) {
+    const float cx = (float)(W - 1) / 2.0f, cy = (float)(H - 1) / 2.0f;
+    const float mx = (float)(W - 1), my = (float)(H - 1);
+    for (int n = 0; n < N; ++n) {
+        for (int y = 0; y < H; ++y) {
+            const float *f = flow + (long)(flowN == 1 ? 0 : n) * 2 * H * W;
+            for (int x = 0; x < W; ++x) {
+                const float fx = f[(long)y * W + x];
+                const float fy = f[(long)H * W + (long)y * W + x];
+                float gx = lin_x[x] + fx / cx;
+                float gy = lin_y[y] + fy / cy;
+                float ix = (gx + 1.0f) * cx;
+                float iy = (gy + 1.0f) * cy;
+                ix = fminf(mx, fmaxf(ix, 0.0f));
+                iy = fminf(my, fmaxf(iy, 0.0f));
+                const float xw = floorf(ix), yn = floorf(iy);
+                const float w = ix - xw, e = 1.0f - w;
+                const float nn = iy - yn, s = 1.0f - nn;
+                const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+                const int x0 = (int)xw, y0 = (int)yn;
+                const int x1 = x0 + 1, y1 = y0 + 1;
+                const int x1ok = x1 <= W - 1, y1ok = y1 <= H - 1;
+                for (int c = 0; c < C; ++c) {
+                    const float *p = im + ((long)n * C + c) * H * W;
+                    const float v00 = p[(long)y0 * W + x0];
+                    const float v01 = x1ok ? p[(long)y0 * W + x1] : 0.0f;
+                    const float v10 = y1ok ? p[(long)y1 * W + x0] : 0.0f;
+                    const float v11 = (x1ok && y1ok) ? p[(long)y1 * W + x1] : 0.0f;
+                    float r = v00 * nw;
+                    r = fmaf(v01, ne, r);
+                    r = fmaf(v10, sw, r);
+                    r = fmaf(v11, se, r);
+                    out[((long)n * C + c) * H * W + (long)y * W + x] = r;
+                }
+            }
+        }
+    }
+}
+
+/* avg_pool2d k=2 s=2 (video_net.py:106-108): (((0+a00)+a01)+a10)+a11) / 4 */
+void pm_avgpool2(const float *x, float *y, int NC, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long job = 0; job < (long)NC * Ho; ++job) {
+        const int oy = (int)(job % Ho);
+        const long nc = job / Ho;
+        const float *r0 = x + (nc * H + 2 * oy) * W, *r1 = r0 + W;
+        float *o = y + (nc * Ho + oy) * Wo;
+        for (int ox = 0; ox < Wo; ++ox) {
+            float s = r0[2 * ox] + r0[2 * ox + 1];
+            s = s + r1[2 * ox];
+            s = s + r1[2 * ox + 1];
+            o[ox] = s / 4.0f;
+        }
+    }
+}
+
+/* bilinear x2 upsampling, align_corners=False (video_net.py:58-63, F.interpolate).
+ * src = max(0.5*(dst+0.5)-0.5, 0); i0 = floor(src) (<= size-1); l1 = src-i0; l0 = 1-l1;
+ * i1 = i0 + (i0 < size-1).  t(row) = fmaf(v[i0], l0x, v[i1]*l1x) ; out = fmaf(t(r0), l0y, t(r1)*l1y)
+ * (ATen's CPU kernel evaluates exactly this on planes of >= ~2^15 outputs; on smaller planes it
+ * takes another path that differs in the last bit — see tests/test_oracle_ops.py). */
+static inline void pm_up2_coef(int d, int size, int *i0, int *i1, float *l0, float *l1) {
+    float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int a = (int)floorf(src);
+    if (a > size - 1) a = size - 1;
+    float lam = src - (float)a;
+    if (lam < 0.0f) lam = 0.0f;
+    if (lam > 1.0f) lam = 1.0f;
+    *i0 = a;
+    *i1 = a + (a < size - 1 ? 1 : 0);
+    *l1 = lam;
+    *l0 = 1.0f - lam;
+}
+void pm_bilinear_up2(const float *x, float *y, int NC, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (long job = 0; job < (long)NC * Ho; ++job) {
+        const int oy = (int)(job % Ho);
+        const long nc = job / Ho;
+        int y0, y1; float ly0, ly1;
+        pm_up2_coef(oy, H, &y0, &y1, &ly0, &ly1);
+        const float *r0 = x + (nc * H + y0) * W, *r1 = x + (nc * H + y1) * W;
+        float *o = y + (nc * Ho + oy) * Wo;
+        for (int ox = 0; ox < Wo; ++ox) {
+            int x0, x1; float lx0, lx1;
+            pm_up2_coef(ox, W, &x0, &x1, &lx0, &lx1);
+            const float t0 = fmaf(r0[x0], lx0, r0[x1] * lx1);
+            const float t1 = fmaf(r1[x0], lx0, r1[x1] * lx1);
+            o[ox] = fmaf(t0, ly0, t1 * ly1);
+        }
+    }
+}
+
+/* bilinear /2 downsampling, align_corners=False (video_net.py:66-71):
+ * src = 2*dst+0.5 -> i0 = 2dst, weights 0.5/0.5 in both directions.
+ * t(row) = v0*0.5 + v1*0.5 ; out = t0*0.5 + t1*0.5 */
+void pm_bilinear_down2(const float *x, float *y, int NC, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long job = 0; job < (long)NC * Ho; ++job) {
+        const int oy = (int)(job % Ho);
+        const long nc = job / Ho;
+        const float *r0 = x + (nc * H + 2 * oy) * W, *r1 = r0 + W;
+        float *o = y + (nc * Ho + oy) * Wo;
+        for (int ox = 0; ox < Wo; ++ox) {
+            const float t0 = r0[2 * ox] * 0.5f + r0[2 * ox + 1] * 0.5f;
+            const float t1 = r1[2 * ox] * 0.5f + r1[2 * ox + 1] * 0.5f;
+            o[ox] = t0 * 0.5f + t1 * 0.5f;
+        }
+    }
+}

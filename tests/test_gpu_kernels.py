@@ -1,0 +1,132 @@
+"""HIP primitives vs the oracle's C restatement: bit-exact (PM-F32 arithmetic spec)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def nhwc(x):  # numpy NCHW -> torch NHWC on device
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cuda()
+
+
+def nchw(t):  # torch NHWC device -> numpy NCHW
+    return t.cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def assert_same(a, b, what):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    neq = a != b
+    if neq.any():
+        i = np.argwhere(neq)[0]
+        raise AssertionError(f"{what}: {neq.sum()} / {a.size} elements differ; first at {tuple(i)}: "
+                             f"{a[tuple(i)]!r} vs {b[tuple(i)]!r}; max abs diff {np.abs(a - b).max()}")
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, K, stride, pad, act, slope, nres
+    (1, 112, 40, 72, 112, 3, 1, 1, 2, 0.2, 0),     # ContextResidual conv (small plane -> 8x16 tiles)
+    (1, 112, 264, 520, 112, 3, 1, 1, 0, 0.0, 2),   # big plane -> 8x32 tiles, ragged edges, 2 residual adds
+    (2, 64, 33, 47, 64, 3, 1, 1, 2, 0.2, 1),       # PostProcess ResBlock, odd sizes, batch 2
+    (1, 8, 36, 60, 32, 7, 1, 3, 1, 0.0, 0),        # SpyNet conv1 (Cin=8: half chunk)
+    (1, 32, 36, 60, 64, 7, 1, 3, 1, 0.0, 0),       # SpyNet conv2
+    (1, 16, 72, 120, 2, 7, 1, 3, 0, 0.0, 0),       # SpyNet conv5 (Cout=2)
+    (1, 16, 64, 64, 1, 3, 1, 1, 0, 0.0, 0),        # PredictUpdate conv4
+    (1, 16, 64, 64, 16, 3, 1, 1, 3, 0.0, 0),       # PredictUpdate conv2 + tanh
+    (1, 64, 64, 96, 64, 3, 2, 1, 2, 0.01, 0),      # stride-2 3x3
+    (1, 64, 64, 96, 64, 1, 2, 0, 0, 0.0, 0),       # stride-2 1x1 (downsample)
+    (1, 256, 18, 30, 192, 1, 1, 0, 0, 0.0, 0),     # four-part prior adaptor 1x1 256->192
+    (1, 128, 20, 36, 128, 3, 1, 1, 2, 0.2, 1),     # masked residual block (weights pre-masked)
+    (1, 32, 40, 64, 3, 3, 1, 1, 0, 0.0, 0),        # LSTM3 conv_in 32->3
+    (1, 1, 64, 80, 16, 3, 1, 1, 3, 0.0, 0),        # small-cin 1->16 + tanh
+    (2, 2, 37, 53, 112, 3, 1, 1, 0, 0.0, 0),       # small-cin 2->112
+    (1, 2, 64, 96, 64, 3, 2, 1, 2, 0.01, 0),       # small-cin stride 2
+    (1, 3, 30, 40, 3, 3, 1, 1, 0, 0.0, 1),         # 3->3 with residual
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_conv2d_bitexact(cuda, case):
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    N, Cin, H, W, Cout, K, S, P, act, slope, nres = case
+    r = _rng(1000 + Cin * 7 + Cout)
+    x = r.standard_normal((N, Cin, H, W), dtype=np.float32) * 3
+    w = (r.standard_normal((Cout, Cin, K, K), dtype=np.float32) * 0.05).astype(np.float32)
+    b = r.standard_normal(Cout, dtype=np.float32)
+    ref = clib.conv2d(x, w, b, S, (P, P))
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    elif act == 2:
+        ref = np.where(ref > 0, ref, ref * np.float32(slope)).astype(np.float32)
+    elif act == 3:
+        ref = clib.tanh(ref)
+    res = [r.standard_normal(ref.shape, dtype=np.float32) for _ in range(nres)]
+    for q in res:
+        ref = ref + q
+    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (P, P))
+    y = conv(nhwc(x), act=act, slope=slope, res1=nhwc(res[0]) if nres > 0 else None,
+             res2=nhwc(res[1]) if nres > 1 else None)
+    torch.cuda.synchronize()
+    assert_same(nchw(y), ref, f"conv {case}")
+
+
+def test_conv2d_denormals_and_specials(cuda):
+    """MFMA f32 must behave as an fmaf chain also on subnormal products / tiny accumulators."""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    r = _rng(5)
+    x = r.standard_normal((1, 16, 32, 32), dtype=np.float32)
+    x[:, ::2] *= np.float32(1e-22)
+    w = r.standard_normal((16, 16, 3, 3), dtype=np.float32) * np.float32(1e-20)
+    b = np.zeros(16, np.float32)
+    ref = clib.conv2d(x, w, b, 1, (1, 1))
+    y = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), 1, (1, 1))(nhwc(x))
+    torch.cuda.synchronize()
+    assert_same(nchw(y), ref, "denormal conv")
+
+
+def test_dwconv_bitexact(cuda):
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    r = _rng(7)
+    x = r.standard_normal((2, 64, 37, 51), dtype=np.float32)
+    w = r.standard_normal((64, 1, 3, 3), dtype=np.float32)
+    b = r.standard_normal(64, dtype=np.float32)
+    ref = clib.dwconv2d(x, w, b)
+    y = ops.DepthwiseConv2d(torch.from_numpy(w), torch.from_numpy(b))(nhwc(x))
+    assert_same(nchw(y), ref, "dwconv")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 64, 96), (2, 1, 37, 53), (1, 3, 36, 60)])
+def test_flow_warp_bitexact(cuda, shape):
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    N, Cc, H, W = shape
+    r = _rng(11)
+    im = (r.random(shape, dtype=np.float32) * 255).astype(np.float32)
+    flow = (r.standard_normal((1, 2, H, W), dtype=np.float32) * 6).astype(np.float32)
+    flow[0, 0, 0, :] = 1000.0   # far outside: border clamp
+    flow[0, 1, :, 0] = -1000.0
+    lx = torch.linspace(-1.0, 1.0, W).numpy(); ly = torch.linspace(-1.0, 1.0, H).numpy()
+    for sign in (1.0, -1.0):
+        ref = clib.flow_warp(im, flow * np.float32(sign), lx, ly)
+        out = ops.flow_warp(torch.from_numpy(im).cuda(), torch.from_numpy(flow).cuda(),
+                            torch.from_numpy(lx).cuda(), torch.from_numpy(ly).cuda(), sign)
+        assert_same(out.cpu().numpy(), ref, f"warp sign {sign}")
+
+
+def test_resample_bitexact(cuda):
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    r = _rng(13)
+    x = (r.standard_normal((2, 3, 36, 60), dtype=np.float32) * 10).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    assert_same(ops.avgpool2(xt).cpu().numpy(), clib.avgpool2(x), "avgpool2")
+    assert_same(ops.bilinear_up2(xt, 2.0).cpu().numpy(), clib.bilinear_up2(x) * np.float32(2), "up2")
+    assert_same(ops.bilinear_down2(xt, 2.0).cpu().numpy(), clib.bilinear_down2(x) / np.float32(2), "down2")
