@@ -1,0 +1,103 @@
+"""GOP driver: the temporal-decomposition loop of the reference's evaluation harness
+(test_pMCTF_flex.py:run_test, lines 131-327) restated as a reusable function over any codec object
+exposing the reference model API (`num_me_stages`, `encode_one_stage`, `inverse_MCTF`).
+
+Used by bench.py (HIP product), the parity tests (oracle vs product) and tools/make_golden.py (the
+real reference, in the build container) so that all three run exactly the same schedule:
+stage s codes pairs (2k*2^s, 2k*2^s + 2^s); dpb is reset per stage; the last stage also codes L;
+then the inverse MCTF runs the stages backwards and PSNR is taken on the un-padded crop.
+"""
+import math
+import os
+
+import torch
+
+
+def psnr(a, b):
+    """test_pMCTF_flex.py:81-84"""
+    mse = torch.mean((a - b) ** 2)
+    return (20 * torch.log10(255.0 / torch.sqrt(mse))).item()
+
+
+def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_decoding=True, psize=128,
+               on_pair=None):
+    """frames: list (len = GOP size, power of two) of [Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] padded tensors.
+    Returns dict(bits[], frames_coded (after forward), results[] per pair in coding order)."""
+    gop = len(frames)
+    stages = int(round(math.log2(gop)))
+    assert 2 ** stages == gop and gop >= 2
+    frames_coded = [None] * gop
+    bits = [None] * gop
+    bits_mv = [None] * gop
+    results = []
+    num_frames = gop
+    for stage_idx in range(stages):
+        num_frames //= 2
+        dpb = {"mv_feature": None, "ref_mv_y": None}
+        for group_idx in range(num_frames):
+            step = 2 ** stage_idx
+            i_ref = group_idx * 2 * step
+            i_cur = i_ref + step
+            if stage_idx == 0:
+                y_ref, c_ref = frames[i_ref]
+                y_cur, c_cur = frames[i_cur]
+            else:
+                y_ref, c_ref, mv_r = frames_coded[i_ref]
+                y_cur, c_cur, mv_c = frames_coded[i_cur]
+                assert mv_r is None and mv_c is None
+            code_lt = (stage_idx + 1) == stages
+            me_num = min(codec.num_me_stages - 1, stage_idx)
+            bin_path = os.path.join(bin_folder, f"{i_cur}.bin")
+            r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur], output_path=bin_path,
+                                       pic_height=pic_height, pic_width=pic_width, stage_idx=me_num,
+                                       code_lt=code_lt, psize=psize, skip_decoding=skip_decoding, dpb=dpb,
+                                       q_index=q_index)
+            frames_coded[i_ref] = [r["L_t"], r["L_tc"], None]
+            frames_coded[i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
+            dpb = r["dpb"]
+            bits[i_cur] = float(r["bit_H"] + r["bit_ME"])
+            bits_mv[i_cur] = float(r["bit_ME"])
+            if code_lt:
+                bits[i_ref] = float(r["bit_L"])
+                bits_mv[i_ref] = 0.0
+            results.append(r)
+            if on_pair is not None:
+                on_pair(stage_idx, i_ref, i_cur, r)
+    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
+
+
+def decode_gop(codec, frames_coded):
+    """Temporal synthesis, test_pMCTF_flex.py:268-291.  Modifies and returns frames_coded."""
+    gop = len(frames_coded)
+    stages = int(round(math.log2(gop)))
+    num_frames = 1
+    for stage_idx in reversed(range(stages)):
+        if stage_idx != stages - 1:
+            num_frames *= 2
+        for group_idx in reversed(range(num_frames)):
+            step = 2 ** stage_idx
+            i_ref = group_idx * 2 * step
+            L_t, L_tc, mv_ref = frames_coded[i_ref]
+            H_t, H_tc, mv_hat = frames_coded[i_ref + step]
+            assert mv_ref is None
+            me_num = min(codec.num_me_stages - 1, stage_idx)
+            ref, cur = codec.inverse_MCTF(L_t, H_t, mv_hat, stage_idx=me_num)
+            ref_c, cur_c = codec.inverse_MCTF(L_tc, H_tc, mv_hat, stage_idx=me_num, downscale=True)
+            frames_coded[i_ref] = [ref, ref_c, None]
+            frames_coded[i_ref + step] = [cur, cur_c, None]
+    return frames_coded
+
+
+def gop_psnr(frames_rec, frames_orig, pic_height, pic_width):
+    """YUV-PSNR (6Y+Cb+Cr)/8 per frame on the un-padded crop, test_pMCTF_flex.py:294-325."""
+    out = []
+    for (rec_y, rec_c, _), (y, c) in zip(frames_rec, frames_orig):
+        ry = torch.round(rec_y.clamp(0, 255.0))[:, :, :pic_height, :pic_width]
+        rc = torch.round(rec_c.clamp(0, 255.0))[:, :, :pic_height // 2, :pic_width // 2]
+        oy = y[:, :, :pic_height, :pic_width]
+        oc = c[:, :, :pic_height // 2, :pic_width // 2]
+        py = psnr(ry, oy)
+        pcb = psnr(rc[0:1], oc[0:1])
+        pcr = psnr(rc[1:2], oc[1:2])
+        out.append({"y": py, "cb": pcb, "cr": pcr, "yuv": (6.0 * py + pcb + pcr) / 8.0})
+    return out

@@ -1,0 +1,103 @@
+"""ORACLE — test infrastructure only; never imported by the product path.
+
+Two interchangeable primitive back-ends for the functional restatement in model.py,
+both operating on torch CPU float32 NCHW tensors:
+
+  TorchK  the ATen CPU ops the reference itself calls (F.conv2d, F.grid_sample, ...).  On the
+          machine that generated tests/golden this reproduces the reference bit for bit; it is
+          how the restatement's control flow is pinned against the real reference.
+  CdefK   the PM-F32 C restatement (oracle/c): fixed summation order, specified transcendentals.
+          The HIP kernels are bit-exact against this back-end.
+
+Elementwise +,-,*,/ , round, clamp, max and comparisons are plain torch ops in both (single IEEE
+roundings, no fusion), and the HIP kernels perform the same single-rounded operations.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import clib
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class TorchK:
+    name = "torch"
+
+    def conv2d(self, x, w, b, stride=1, padding=0, groups=1):
+        return F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
+
+    def tanh(self, x):
+        return torch.tanh(x)
+
+    def sigmoid(self, x):
+        return torch.sigmoid(x)
+
+    def lin_tables(self, H, W):
+        return torch.linspace(-1.0, 1.0, W), torch.linspace(-1.0, 1.0, H)
+
+    def flow_warp(self, im, flow):
+        # pMCTF/layers/video/video_net.py:32-50
+        N, _, H, W = flow.size()
+        lx, ly = self.lin_tables(H, W)
+        hor = lx.view(1, 1, 1, W).expand(N, -1, H, -1)
+        ver = ly.view(1, 1, H, 1).expand(N, -1, -1, W)
+        grid = torch.cat([hor, ver], 1)
+        fl = torch.cat([flow[:, 0:1] / ((im.size(3) - 1.0) / 2.0), flow[:, 1:2] / ((im.size(2) - 1.0) / 2.0)], 1)
+        grid = grid + fl
+        return F.grid_sample(im, grid.permute(0, 2, 3, 1), mode="bilinear", padding_mode="border",
+                             align_corners=True)
+
+    def avg_pool2(self, x):
+        return F.avg_pool2d(x, kernel_size=2, stride=2)
+
+    def bilinear_up2(self, x):
+        return F.interpolate(x, (x.size(2) * 2, x.size(3) * 2), mode="bilinear", align_corners=False)
+
+    def bilinear_down2(self, x):
+        return F.interpolate(x, (x.size(2) // 2, x.size(3) // 2), mode="bilinear", align_corners=False)
+
+    def build_indexes(self, tables, scales):
+        return tables.build_indexes_torch(scales)
+
+
+class CdefK(TorchK):
+    name = "cdef"
+
+    def conv2d(self, x, w, b, stride=1, padding=0, groups=1):
+        pad = padding if isinstance(padding, (tuple, list)) else (padding, padding)
+        stride = stride[0] if isinstance(stride, (tuple, list)) else stride
+        xn = x.detach().numpy()
+        wn = w.detach().numpy()
+        bn = None if b is None else b.detach().numpy()
+        if groups == 1:
+            return _t(clib.conv2d(xn, wn, bn, stride, pad))
+        assert groups == x.size(1) == w.size(0) and w.size(1) == 1 and stride == 1 and pad[0] == w.size(2) // 2
+        return _t(clib.dwconv2d(xn, wn, bn))
+
+    def tanh(self, x):
+        return _t(clib.tanh(x.numpy()))
+
+    def sigmoid(self, x):
+        return _t(clib.sigmoid(x.numpy()))
+
+    def flow_warp(self, im, flow):
+        N, _, H, W = im.shape
+        lx, ly = self.lin_tables(H, W)
+        if flow.size(0) != 1 and flow.size(0) != N:
+            raise ValueError("flow batch")
+        return _t(clib.flow_warp(im.numpy(), flow.numpy(), lx.numpy(), ly.numpy()))
+
+    def avg_pool2(self, x):
+        return _t(clib.avgpool2(x.numpy()))
+
+    def bilinear_up2(self, x):
+        return _t(clib.bilinear_up2(x.numpy()))
+
+    def bilinear_down2(self, x):
+        return _t(clib.bilinear_down2(x.numpy()))
+
+    def build_indexes(self, tables, scales):
+        return tables.build_indexes_cdef(scales)

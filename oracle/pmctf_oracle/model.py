@@ -1,0 +1,653 @@
+"""ORACLE — test infrastructure only; never imported by the product path.
+
+Functional CPU restatement of the reference's encode hot path over a plain
+state_dict.  Every function cites the reference lines it follows.  Numeric primitives come from a
+back-end in kernels.py (TorchK = the ATen ops the reference calls; CdefK = the PM-F32 C
+restatement that the HIP kernels match bit for bit).
+
+Pinning: tools/make_golden.py imports the real reference in the build container, runs it on the
+build's deterministic weights and writes tests/golden/*.npz; tests/test_oracle_vs_golden.py checks
+this restatement against those fixtures.
+"""
+import math
+import os
+import struct
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import entropy
+from .kernels import CdefK, TorchK
+
+
+def get_padding_size(height, width, p=64):
+    """pMCTF/utils/stream_helper.py:23-32"""
+    new_h = (height + p - 1) // p * p
+    new_w = (width + p - 1) // p * p
+    return 0, new_w - width, 0, new_h - height
+
+
+def get_rounded_q(q_scale):
+    """pMCTF/utils/stream_helper.py:41-45"""
+    q_scale = np.clip(q_scale, 0.01, 655.)
+    q_index = int(np.round(q_scale * 100))
+    return q_index / 100, q_index
+
+
+def encode_p_bytes(string, mv_y_q_index):
+    """stream_helper.py:181-186: >H q_index, >I length, payload"""
+    return struct.pack(">H", mv_y_q_index) + struct.pack(">I", len(string)) + string
+
+
+def encode_image_bytes(height, width, num_channels, bit_stream):
+    """stream_helper.py:201-207: >III h,w,c ; >I length ; payload"""
+    return struct.pack(">III", height, width, num_channels) + struct.pack(">I", len(bit_stream)) + bit_stream
+
+
+QP_NUM = 21  # pMCTF_L.py:217-219, pWave.py:227-229
+
+
+def get_curr_q(q_scale, q_index):
+    """pMCTF_L.py:195-209 / pWave.py:209-225 (torch CPU scalar arithmetic on the (2,1,1,1) parameter)"""
+    min_q = q_scale[0:1]
+    max_q = q_scale[1:2]
+    step = (torch.log(max_q) - torch.log(min_q)) / (QP_NUM - 1)
+    return torch.exp(torch.log(min_q) + step * q_index)
+
+
+class Oracle:
+    def __init__(self, state_dict, num_me_stages=1, backend="cdef", decomp_levels=4):
+        self.K = CdefK() if backend == "cdef" else TorchK()
+        self.num_me_stages = num_me_stages
+        self.L = decomp_levels
+        sd = {k: v.detach().clone().float() for k, v in state_dict.items()}
+        # MaskedConv2d.forward multiplies weight.data by the mask in place (layers/layers.py:49-51)
+        for k in list(sd.keys()):
+            if k.endswith(".mask"):
+                sd[k[:-5] + ".weight"] = sd[k[:-5] + ".weight"] * sd[k]
+        self.sd = sd
+        self.tables = entropy.GaussianTables()
+        self.bit_est = [entropy.BitEstimatorTables(sd, f"mv_bit_est.{i}.") for i in range(num_me_stages)]
+        self.trace = None          # list of (symbols, indexes) pushes of the current stream
+        self.taps = {}             # named intermediates for parity tests
+        self.tap_enabled = False
+
+    # ------------------------------------------------------------------ helpers
+    def tap(self, name, t):
+        if self.tap_enabled:
+            self.taps[name] = t.detach().clone()
+
+    def conv(self, p, x, stride=1, padding=0, groups=1):
+        return self.K.conv2d(x, self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride=stride, padding=padding,
+                             groups=groups)
+
+    # ------------------------------------------------------------------ a6: PredictUpdate, lifting_1d.py:36-49
+    def predict_update(self, p, x):
+        conv1 = self.conv(p + ".conv1", x, padding=1)
+        t = self.K.tanh(conv1)
+        t = self.conv(p + ".conv2", t, padding=1)
+        t = self.K.tanh(t)
+        t = self.conv(p + ".conv3", t, padding=1)
+        t = conv1 + t
+        return self.conv(p + ".conv4", t, padding=1)
+
+    # wavelet_transform_temporal_mctf.py:27-45
+    def predict_filter(self, stage, x):
+        tmp = self.predict_update(f"temporal_filtering.{stage}.P_t", x) * 0.1
+        x = x + tmp
+        return x * torch.tensor(1 / math.sqrt(2))
+
+    def update_filter(self, stage, x):
+        tmp = self.predict_update(f"temporal_filtering.{stage}.U_t", x) * 0.1
+        x = x + tmp
+        return x * torch.tensor(0.5)
+
+    # ------------------------------------------------------------------ a5/a7: pMCTF_L.py:297-330
+    def forward_MCTF(self, ref, cur, mv_hat, stage_idx=0):
+        me = min(self.num_me_stages - 1, stage_idx)
+        if ref.size(0) > mv_hat.size(0):
+            mv_hat = mv_hat.tile((ref.size(0), 1, 1, 1))
+        pred = self.K.flow_warp(ref, mv_hat)
+        pred = self.predict_filter(me, pred)
+        H_t = cur - pred
+        inv = self.K.flow_warp(H_t, -mv_hat)
+        inv = self.update_filter(me, inv)
+        L_t = ref + inv
+        return L_t, H_t, pred, inv
+
+    def inverse_MCTF(self, L_t, H_t, mv_hat, downscale=False, stage_idx=0):
+        me = min(self.num_me_stages - 1, stage_idx)
+        if downscale:
+            mv_hat = self.K.bilinear_down2(mv_hat) / 2
+        if L_t.size(0) > mv_hat.size(0):
+            mv_hat = mv_hat.tile((L_t.size(0), 1, 1, 1))
+        inv = self.K.flow_warp(H_t, -mv_hat)
+        inv = self.update_filter(me, inv)
+        ref = L_t - inv
+        pred = self.K.flow_warp(ref, mv_hat)
+        pred = self.predict_filter(me, pred)
+        cur = H_t + pred
+        return ref, cur
+
+    # ------------------------------------------------------------------ a3: SpyNet, video_net.py:74-121
+    def me_basic(self, level, x):
+        p = f"optic_flow.moduleBasic.{level}"
+        x = F.relu(self.conv(p + ".conv1", x, padding=3))
+        x = F.relu(self.conv(p + ".conv2", x, padding=3))
+        x = F.relu(self.conv(p + ".conv3", x, padding=3))
+        x = F.relu(self.conv(p + ".conv4", x, padding=3))
+        return self.conv(p + ".conv5", x, padding=3)
+
+    def spynet(self, im1, im2, Lv=6):
+        im1_list, im2_list = [im1], [im2]
+        for level in range(Lv - 1):
+            im1_list.append(self.K.avg_pool2(im1_list[level]))
+            im2_list.append(self.K.avg_pool2(im2_list[level]))
+        shape_fine = im2_list[Lv - 1].size()
+        flow = torch.zeros([im1.size(0), 2, shape_fine[2] // 2, shape_fine[3] // 2], dtype=im1.dtype)
+        for level in range(Lv):
+            flow_up = self.K.bilinear_up2(flow) * 2.0
+            idx = Lv - 1 - level
+            inp = torch.cat([im1_list[idx], self.K.flow_warp(im2_list[idx], flow_up), flow_up], 1)
+            flow = flow_up + self.me_basic(level, inp)
+            self.tap(f"spynet.flow{level}", flow)
+        return flow
+
+    # ------------------------------------------------------------------ video/layers.py building blocks
+    def res_block_stride(self, p, x, stride=2):
+        """ResidualBlockWithStride, video/layers.py:46-77"""
+        out = self.conv(p + ".conv1", x, stride=stride, padding=1)
+        out = F.leaky_relu(out, 0.01)
+        out = self.conv(p + ".conv2", out, padding=1)
+        out = F.leaky_relu(out, 0.1)
+        identity = self.conv(p + ".downsample", x, stride=stride) if stride != 1 else x
+        return out + identity
+
+    def res_block_up(self, p, x):
+        """ResidualBlockUpsample, video/layers.py:80-105"""
+        out = F.pixel_shuffle(self.conv(p + ".subpel_conv.0", x), 2)
+        out = F.leaky_relu(out, 0.01)
+        out = self.conv(p + ".conv", out, padding=1)
+        out = F.leaky_relu(out, 0.1)
+        identity = F.pixel_shuffle(self.conv(p + ".upsample.0", x), 2)
+        return out + identity
+
+    def depth_conv(self, p, x):
+        """DepthConv (stride 1), video/layers.py:108-136"""
+        identity = x
+        if (p + ".adaptor.weight") in self.sd:
+            identity = self.conv(p + ".adaptor", x)
+        out = F.leaky_relu(self.conv(p + ".conv1.0", x), 0.01)
+        C = out.size(1)
+        out = self.conv(p + ".depth_conv", out, padding=1, groups=C)
+        out = self.conv(p + ".conv2", out)
+        return out + identity
+
+    def conv_ffn(self, p, x):
+        """ConvFFN, video/layers.py:139-153"""
+        t = F.leaky_relu(self.conv(p + ".conv.0", x), 0.1)
+        t = F.leaky_relu(self.conv(p + ".conv.2", t), 0.1)
+        return x + t
+
+    def conv_ffn3(self, p, x):
+        """ConvFFN3, video/layers.py:155-168"""
+        x1, x2 = self.conv(p + ".conv", x).chunk(2, 1)
+        out = F.leaky_relu(x1, 0.1) + F.leaky_relu(x2, 0.01)
+        return x + self.conv(p + ".conv_out", out)
+
+    def depth_conv_block(self, p, x):
+        """DepthConvBlock, video/layers.py:171-181"""
+        return self.conv_ffn(p + ".block.1", self.depth_conv(p + ".block.0", x))
+
+    def depth_conv_block4(self, p, x):
+        """DepthConvBlock4, video/layers.py:184-193"""
+        return self.conv_ffn3(p + ".block.1", self.depth_conv(p + ".block.0", x))
+
+    # ------------------------------------------------------------------ MV codec, video_net.py:124-191
+    def mv_enc(self, s, x, context, quant_step):
+        p = f"mv_encoder.{s}"
+        out = self.res_block_stride(p + ".enc_1.0", x)
+        out = self.depth_conv_block(p + ".enc_1.1", out)
+        out = out * quant_step
+        out = self.res_block_stride(p + ".enc_2", out)
+        if context is None:
+            out = self.depth_conv_block(p + ".adaptor_0", out)
+        else:
+            out = self.depth_conv_block(p + ".adaptor_1", torch.cat((out, context), dim=1))
+        out = self.res_block_stride(p + ".enc_3.0", out)
+        out = self.depth_conv_block(p + ".enc_3.1", out)
+        return self.conv(p + ".enc_3.2", out, stride=2, padding=1)
+
+    def mv_dec(self, s, x, quant_step):
+        p = f"mv_decoder.{s}"
+        f = self.depth_conv_block(p + ".dec_1.0", x)
+        f = self.res_block_up(p + ".dec_1.1", f)
+        f = self.depth_conv_block(p + ".dec_1.2", f)
+        f = self.res_block_up(p + ".dec_1.3", f)
+        feature = self.depth_conv_block(p + ".dec_1.4", f)
+        out = self.res_block_up(p + ".dec_2", feature)
+        out = out * quant_step
+        out = self.depth_conv_block(p + ".dec_3.0", out)
+        mv = F.pixel_shuffle(self.conv(p + ".dec_3.1.0", out), 2)
+        return mv, feature
+
+    def mv_hyper_enc(self, s, x):
+        p = f"mv_hyper_prior_encoder.{s}"
+        x = self.depth_conv_block4(p + ".0", x)
+        x = self.conv(p + ".1", x, stride=2, padding=1)
+        x = F.leaky_relu(x, 0.01)
+        return self.conv(p + ".3", x, stride=2, padding=1)
+
+    def mv_hyper_dec(self, s, x):
+        p = f"mv_hyper_prior_decoder.{s}"
+        x = self.res_block_up(p + ".0", x)
+        x = self.res_block_up(p + ".1", x)
+        return self.depth_conv_block4(p + ".2", x)
+
+    def mv_prior_param_decoder(self, mv_z_hat, dpb, s):
+        """pMCTF_L.py:232-241"""
+        params = self.mv_hyper_dec(s, mv_z_hat)
+        ref_mv_y = dpb["ref_mv_y"]
+        if ref_mv_y is None:
+            params = self.depth_conv_block(f"mv_y_prior_fusion_adaptor_0.{s}", params)
+        else:
+            params = self.depth_conv_block(f"mv_y_prior_fusion_adaptor_1.{s}", torch.cat((params, ref_mv_y), dim=1))
+        params = self.depth_conv_block(f"mv_y_prior_fusion.{s}.0", params)
+        return self.depth_conv_block(f"mv_y_prior_fusion.{s}.1", params)
+
+    @staticmethod
+    def masks4(H, W):
+        """get_mask_four_parts, four_part_prior.py:51-78 / context_fusion_4step.py:92-119"""
+        out = []
+        for m in (((1, 0), (0, 0)), ((0, 1), (0, 0)), ((0, 0), (1, 0)), ((0, 0), (0, 1))):
+            mm = torch.tensor(m, dtype=torch.float32).repeat((H + 1) // 2, (W + 1) // 2)[:H, :W]
+            out.append(mm[None, None])
+        return out
+
+    @staticmethod
+    def process_with_mask(y, scales, means, mask):
+        """four_part_prior.py:40-49 / context_fusion_4step.py:127-137"""
+        scales_hat = scales * mask
+        means_hat = means * mask
+        y_res = (y - means_hat) * mask
+        y_q = torch.round(y_res)
+        y_hat = y_q + means_hat
+        return y_res, y_q, y_hat, scales_hat
+
+    def mv_spatial_prior(self, s, adaptor, params):
+        x = self.conv(f"mv_y_spatial_prior_adaptor_{adaptor}.{s}", params)
+        for i in range(3):
+            x = self.depth_conv_block(f"mv_y_spatial_prior.{s}.{i}", x)
+        return x.chunk(8, 1)
+
+    def compress_four_part_prior(self, s, y, common_params):
+        """MVCoderQuad.forward_four_part_prior(write=True), four_part_prior.py:89-208 (enc_dec_quant=True)"""
+        quant_step, scales, means = common_params.chunk(3, 1)
+        quant_step = torch.max(quant_step, torch.ones_like(quant_step) * 0.5)      # LowerBound, video_net.py:14-20
+        q_enc = 1. / quant_step
+        q_dec = quant_step
+        _, _, H, W = y.size()
+        m0, m1, m2, m3 = self.masks4(H, W)
+        y = y * q_enc
+        y_0, y_1, y_2, y_3 = y.chunk(4, 1)
+        s0, s1, s2, s3 = scales.chunk(4, 1)
+        u0, u1, u2, u3 = means.chunk(4, 1)
+        pm = self.process_with_mask
+        _, q00, h00, sh00 = pm(y_0, s0, u0, m0)
+        _, q11, h11, sh11 = pm(y_1, s1, u1, m1)
+        _, q22, h22, sh22 = pm(y_2, s2, u2, m2)
+        _, q33, h33, sh33 = pm(y_3, s3, u3, m3)
+        so_far = torch.cat((h00, h11, h22, h33), dim=1)
+        s0, s1, s2, s3, u0, u1, u2, u3 = self.mv_spatial_prior(s, 1, torch.cat((so_far, common_params), dim=1))
+        _, q03, h03, sh03 = pm(y_0, s0, u0, m3)
+        _, q12, h12, sh12 = pm(y_1, s1, u1, m2)
+        _, q21, h21, sh21 = pm(y_2, s2, u2, m1)
+        _, q30, h30, sh30 = pm(y_3, s3, u3, m0)
+        so_far = so_far + torch.cat((h03, h12, h21, h30), dim=1)
+        s0, s1, s2, s3, u0, u1, u2, u3 = self.mv_spatial_prior(s, 2, torch.cat((so_far, common_params), dim=1))
+        _, q02, h02, sh02 = pm(y_0, s0, u0, m2)
+        _, q13, h13, sh13 = pm(y_1, s1, u1, m3)
+        _, q20, h20, sh20 = pm(y_2, s2, u2, m0)
+        _, q31, h31, sh31 = pm(y_3, s3, u3, m1)
+        so_far = so_far + torch.cat((h02, h13, h20, h31), dim=1)
+        s0, s1, s2, s3, u0, u1, u2, u3 = self.mv_spatial_prior(s, 3, torch.cat((so_far, common_params), dim=1))
+        _, q01, h01, sh01 = pm(y_0, s0, u0, m1)
+        _, q10, h10, sh10 = pm(y_1, s1, u1, m0)
+        _, q23, h23, sh23 = pm(y_2, s2, u2, m3)
+        _, q32, h32, sh32 = pm(y_3, s3, u3, m2)
+        # combine_four_parts (:80-87)
+        y_hat = torch.cat((h00 + h01 + h02 + h03, h10 + h11 + h12 + h13, h20 + h21 + h22 + h23,
+                           h30 + h31 + h32 + h33), dim=1)
+        y_hat = y_hat * q_dec
+        qw = [q00 + q11 + q22 + q33, q03 + q12 + q21 + q30, q02 + q13 + q20 + q31, q01 + q10 + q23 + q32]
+        sw = [sh00 + sh11 + sh22 + sh33, sh03 + sh12 + sh21 + sh30, sh02 + sh13 + sh20 + sh31,
+              sh01 + sh10 + sh23 + sh32]
+        return qw, sw, y_hat
+
+    # ------------------------------------------------------------------ entropy hand-off (a16)
+    def new_stream(self):
+        self.trace = []
+        self.ec = entropy.EntropyCoder(trace=self.trace)
+        self.ec.reset()
+
+    def gaussian_encode(self, x, scales):
+        """GaussianEncoder.encode, entropy_models.py:275-278"""
+        idx = self.K.build_indexes(self.tables, scales)
+        self.ec.encode_with_indexes(x.reshape(-1), idx.reshape(-1), *self.tables.cdf_info())
+
+    def finish_stream(self):
+        self.ec.flush()
+        return self.ec.get_encoded_stream()
+
+    # ------------------------------------------------------------------ a2: compress_mv, pMCTF_L.py:448-495
+    def get_mv_y_q(self, q_index, s):
+        enc = get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index)
+        enc, _ = get_rounded_q(enc.numpy())
+        dec = get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index)
+        dec, _ = get_rounded_q(dec.numpy())
+        return enc, dec
+
+    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0):
+        s = min(self.num_me_stages - 1, stage_idx)
+        q_enc, q_dec = self.get_mv_y_q(q_index, s)
+        mv_x = cur_y.tile((1, 3, 1, 1)) / 255
+        mv_ref = ref_y.tile((1, 3, 1, 1)) / 255
+        est_mv = self.spynet(mv_x, mv_ref)
+        self.tap("est_mv", est_mv)
+        mv_y = self.mv_enc(s, est_mv, dpb["mv_feature"], q_enc)
+        self.tap("mv_y", mv_y)
+        mv_z = self.mv_hyper_enc(s, mv_y)
+        mv_z_hat = torch.round(mv_z)
+        self.tap("mv_z_hat", mv_z_hat)
+        mv_params = self.mv_prior_param_decoder(mv_z_hat, dpb, s)
+        self.tap("mv_params", mv_params)
+        qw, sw, mv_y_hat = self.compress_four_part_prior(s, mv_y, mv_params)
+        mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        self.new_stream()
+        be = self.bit_est[s]
+        idx = be.build_indexes(mv_z_hat.size())
+        self.ec.encode_with_indexes(mv_z_hat.reshape(-1), idx.reshape(-1), *be.cdf_info())
+        for q, sc in zip(qw, sw):
+            self.gaussian_encode(q, sc)
+        bit_stream = self.finish_stream()
+        return {"bit_stream": bit_stream, "mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat,
+                "trace": self.trace}
+
+    # ------------------------------------------------------------------ a10: learned lifting DWT
+    def lift_skip(self, p, x):
+        """reflectionPadSkip + 3x1 conv, lifting_1d.py:98,105-106"""
+        xp = F.pad(x, (0, 0, 1, 1), mode="reflect")
+        return self.conv(p, xp)
+
+    def lift_branch(self, wt, name_conv, name_pu, x):
+        skip = self.lift_skip(f"{wt}.{name_conv}", x)
+        t = self.predict_update(f"{wt}.{name_pu}", skip / 256.0) * 256.0
+        return skip + t * 0.1
+
+    def forward_lift(self, wt, x):
+        """iWave1D.forward_lift, lifting_1d.py:103-145"""
+        x_e, x_o = x[:, :, ::2, :], x[:, :, 1::2, :]
+        x_o = x_o + self.lift_branch(wt, "conv_P1", "P_1", x_e)
+        x_e = x_e + self.lift_branch(wt, "conv_U1", "U_1", x_o)
+        x_o = x_o + self.lift_branch(wt, "conv_P2", "P_2", x_e)
+        x_e = x_e + self.lift_branch(wt, "conv_U2", "U_2", x_o)
+        x_e = x_e * torch.tensor(1.149604398860241)
+        x_o = x_o * torch.tensor(0.869864451624781)
+        return x_e, x_o
+
+    def backward_lift(self, wt, l, h):
+        """iWave1D.backward_lift, lifting_1d.py:147-189"""
+        l = l / torch.tensor(1.149604398860241)
+        h = h / torch.tensor(0.869864451624781)
+        l = l - self.lift_branch(wt, "conv_U2", "U_2", h)
+        h = h - self.lift_branch(wt, "conv_P2", "P_2", l)
+        l = l - self.lift_branch(wt, "conv_U1", "U_1", h)
+        h = h - self.lift_branch(wt, "conv_P1", "P_1", l)
+        dims = list(l.size())
+        dims[2] *= 2
+        x = torch.zeros(dims)
+        x[:, :, ::2, :] = l
+        x[:, :, 1::2, :] = h
+        return x
+
+    def forward_lift_2d(self, coder, x):
+        """LiftingScheme2D.forward_lift_2d, wavelet_transform.py:25-42 (lift_v is lift_h)"""
+        wt = f"{coder}.wavelet_transform.lift_h"
+        P = lambda t: t.permute((0, 1, 3, 2))
+        l, h = self.forward_lift(wt, x)
+        ll, lh = self.forward_lift(wt, P(l))
+        hl, hh = self.forward_lift(wt, P(h))
+        return {"ll": P(ll), "lh": P(lh), "hl": P(hl), "hh": P(hh)}
+
+    def backward_lift_2d(self, coder, sb):
+        """wavelet_transform.py:44-57"""
+        wt = f"{coder}.wavelet_transform.lift_h"
+        P = lambda t: t.permute((0, 1, 3, 2))
+        l = P(self.backward_lift(wt, P(sb["ll"]), P(sb["lh"])))
+        h = P(self.backward_lift(wt, P(sb["hl"]), P(sb["hh"])))
+        return self.backward_lift(wt, l, h)
+
+    # ------------------------------------------------------------------ a11: LL entropy parameters, context_fusion.py:100-128
+    def context_fusion_ll(self, coder, x):
+        p = f"{coder}.context_fusion.{self.L - 1}.ll"
+        x = self.conv(p + ".maskedConv1", x, padding=1)
+        conv1 = x
+        for i in range(2):
+            q = f"{p}.residualBlocks.{i}"
+            o = self.conv(q + ".conv1", x, padding=1)
+            o = F.leaky_relu(o, 0.2)
+            o = self.conv(q + ".conv2", o, padding=1)
+            x = o + x
+        x = x + conv1
+        x = self.conv(p + ".maskedConv2", x, padding=1)
+        x = F.leaky_relu(x, 0.2)
+        x = F.leaky_relu(self.conv(p + ".convs.0", x), 0.2)
+        x = F.leaky_relu(self.conv(p + ".convs.1", x), 0.2)
+        return self.conv(p + ".convs.2", x)
+
+    # ------------------------------------------------------------------ a12: four-step context fusion
+    def context_residual(self, p, x):
+        """ContextResidual, context_fusion_4step.py:9-20"""
+        o = self.conv(p + ".conv1", x, padding=1)
+        o = F.leaky_relu(o, 0.2)
+        o = self.conv(p + ".conv2", o, padding=1)
+        return o + x
+
+    def fusion_compress(self, p, x, context, prev_subband):
+        """ContextFusionFourStep.forward(write=True), context_fusion_4step.py:139-191"""
+        if prev_subband is not None:
+            prev = F.interpolate(prev_subband, scale_factor=2, mode="nearest")
+            prev = self.conv(p + ".lower_level_subband.1", prev, padding=1)
+            context = torch.cat((context, prev), dim=1)
+        context = self.conv(p + ".conv1_context", context, padding=1)
+        context = self.context_residual(p + ".y_hierarchical_prior_enc.0", context)
+        context = self.context_residual(p + ".y_hierarchical_prior_enc.1", context)
+        hp = self.depth_conv_block(p + ".y_hierarchical_prior_out", context)
+        scales, means = hp.chunk(2, dim=1)
+        _, _, H, W = x.size()
+        masks = self.masks4(H, W)
+        qs, ss = [], []
+        _, q, x_hat, sh = self.process_with_mask(x, scales, means, masks[0])
+        qs.append(q); ss.append(sh)
+        so_far = x_hat
+        for step in (1, 2, 3):
+            t = self.conv(f"{p}.y_spatial_prior_{step}.0", so_far, padding=1)
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t)
+            t = t + context
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.0", t)
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
+            params = self.conv(f"{p}.y_spatial_prior_{step}_out.2", t)
+            scales, means = params.chunk(2, dim=1)
+            _, q, x_hat, sh = self.process_with_mask(x, scales, means, masks[step])
+            qs.append(q); ss.append(sh)
+            so_far = so_far + x_hat
+        return qs, ss, so_far
+
+    # ------------------------------------------------------------------ a13: conv-LSTM subband context
+    def lstm(self, p, x, hidden, cell):
+        """LSTM2D.forward, long_context.py:16-33"""
+        x = self.conv(p + ".conv_in", x, padding=1)
+        hidden = self.conv(p + ".conv_hidden", hidden, padding=1)
+        x_h = x + hidden
+        forget_gate = self.K.sigmoid(x_h)
+        input_gate = self.K.sigmoid(x_h)
+        c_tilde = self.K.tanh(x_h)
+        cell = forget_gate * cell + input_gate * c_tilde
+        o = self.K.sigmoid(x_h)
+        hidden = o * self.K.tanh(cell)
+        return hidden, cell
+
+    def ctx_init(self, size):
+        """SubbandContext.init_sequential, long_context.py:156-170"""
+        N, _, H, W = size
+        self.l3 = [torch.zeros(N, 3, H, W), torch.zeros(N, 1, H, W)]
+        self.l1 = [torch.zeros(N, 32, H, W), torch.zeros(N, 32, H, W)]
+        self.l2 = [torch.zeros(N, 32, H, W), torch.zeros(N, 32, H, W)]
+
+    def ctx_upsample(self, p, x):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        return self.conv(p + ".conv", x, padding=1)
+
+    def ctx_forward_one_subband(self, coder, subband, name, lvl):
+        """SubbandContext.forward_one_subband, long_context.py:199-224"""
+        p = f"{coder}.context_prediction"
+        h1, c1 = self.lstm(p + ".LSTM1", subband, *self.l1)
+        h2, c2 = self.lstm(p + ".LSTM2", h1, *self.l2)
+        h3, c3 = self.lstm(p + ".LSTM3", h2, *self.l3)
+        self.l1, self.l2, self.l3 = [h1, c1], [h2, c2], [h3, c3]
+        if name == "hh" and lvl > 0:
+            self.l1 = [self.ctx_upsample(f"{p}.deconv_h1.{lvl - 1}", self.l1[0]),
+                       self.ctx_upsample(f"{p}.deconv_c1.{lvl - 1}", self.l1[1])]
+            self.l2 = [self.ctx_upsample(f"{p}.deconv_h2.{lvl - 1}", self.l2[0]),
+                       self.ctx_upsample(f"{p}.deconv_c2.{lvl - 1}", self.l2[1])]
+            self.l3 = [self.ctx_upsample(f"{p}.deconv_h3.{lvl - 1}", self.l3[0]),
+                       self.ctx_upsample(f"{p}.deconv_c3.{lvl - 1}", self.l3[1])]
+        return self.l3[0]
+
+    # ------------------------------------------------------------------ a14: PostProcess, postprocessing.py:35-44
+    def post_process(self, coder, x):
+        p = f"{coder}.dequantModule"
+        tmp = self.conv(p + ".conv1", x, padding=1)
+        conv1 = tmp
+        for i in range(6):
+            q = f"{p}.resBlocks.{i}"
+            o = self.conv(q + ".conv1", tmp, padding=1)
+            o = F.leaky_relu(o, 0.2)
+            o = self.conv(q + ".conv2", o, padding=1)
+            tmp = o + tmp
+        tmp = self.conv(p + ".conv2", tmp, padding=1) + conv1
+        tmp = self.conv(p + ".conv3", tmp, padding=1)
+        return x + tmp
+
+    # ------------------------------------------------------------------ a9: pWave.compress (skip_decoding=True), pWave.py:381-463
+    def pwave_compress(self, coder, x, sideinfo, q_index, qp_scale=None):
+        _, num_channels, height, width = sideinfo
+        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+        if qp_scale is not None:
+            q_scale = q_scale * qp_scale
+            q_scale_ll = q_scale_ll * qp_scale
+        clip = 8192.
+        # encode(): 4-level DWT (:139-148)
+        y = {}
+        ll = x
+        for lvl in range(self.L):
+            y[lvl] = self.forward_lift_2d(coder, ll)
+            ll = y[lvl]["ll"]
+        self.tap(f"{coder}.ll", ll)
+        subbands_hat = {lvl: {} for lvl in range(self.L)}
+        ll = (ll * q_scale_ll).clamp(-clip, clip).round()
+        self.new_stream()
+        params = self.context_fusion_ll(coder, ll)
+        scales, means = params.chunk(2, dim=1)
+        y_q = torch.round(ll)                   # CompressionModel.process, gaussian_model.py:59-63
+        ll_res = y_q - means
+        ll_hat = (ll_res.round() + means).round()
+        self.gaussian_encode(ll_res.round(), scales)
+        subbands_hat[self.L - 1]["ll"] = ll_hat
+        self.ctx_init(list(ll.size()))
+        context = self.ctx_forward_one_subband(coder, ll_hat, "ll", self.L - 1)
+        for lvl in range(self.L - 1, -1, -1):
+            for sidx, sb in enumerate(["lh", "hl", "hh"]):
+                ctx = context.chunk(3, dim=1)[sidx]
+                prev = subbands_hat[lvl + 1][sb] if lvl < self.L - 1 else None
+                s_curr = (y[lvl][sb] * q_scale).clamp(-clip, clip)
+                qs, ss, s_hat = self.fusion_compress(f"{coder}.context_fusion.{lvl}.{sb}", s_curr, ctx, prev)
+                subbands_hat[lvl][sb] = s_hat
+                self.tap(f"{coder}.s_hat.{lvl}.{sb}", s_hat)
+                for q, sc in zip(qs, ss):
+                    self.gaussian_encode(q, sc)
+                context = self.ctx_forward_one_subband(coder, s_hat, sb, lvl)
+        # dequantize (:191-202) + decode (:150-157)
+        rec = {lvl: {} for lvl in range(self.L)}
+        for lvl in range(self.L - 1, -1, -1):
+            for sb in (["ll", "lh", "hl", "hh"] if lvl == self.L - 1 else ["lh", "hl", "hh"]):
+                rec[lvl][sb] = subbands_hat[lvl][sb] / (q_scale_ll if sb == "ll" else q_scale)
+        out = None
+        for lvl in range(self.L - 1, -1, -1):
+            out = self.backward_lift_2d(coder, rec[lvl])
+            if lvl > 0:
+                rec[lvl - 1]["ll"] = out
+        self.tap(f"{coder}.idwt", out)
+        x_hat = self.post_process(coder, out / 256.0) * 256.0
+        bit_stream = self.finish_stream()
+        data = encode_image_bytes(height, width, num_channels, bit_stream)
+        return x_hat, data, self.trace
+
+    # ------------------------------------------------------------------ a8: compress_one_stage, pMCTF_L.py:398-420
+    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, sideinfo, stage_idx=0, q_index=0):
+        if ischroma:
+            mv_hat = self.K.bilinear_down2(mv_hat) / 2
+        L_t, H_t, pred, inv = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        H_hat, h_bytes, h_trace = self.pwave_compress("hp_coder", H_t, sideinfo, q_index, qp_scale)
+        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": H_hat, "H_bytes": h_bytes, "H_trace": h_trace,
+               "L_t_hat": None, "L_bytes": None, "L_trace": None}
+        if code_lt:
+            L_hat, l_bytes, l_trace = self.pwave_compress("lp_coder", L_t, sideinfo, q_index)
+            out.update({"L_t_hat": L_hat, "L_bytes": l_bytes, "L_trace": l_trace})
+        return out
+
+    # ------------------------------------------------------------------ a1: encode_one_stage write branch, pMCTF_L.py:553-637
+    def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
+                         psize=128, skip_decoding=True, stage_idx=0, q_index=0, me_downsample=1):
+        assert skip_decoding and me_downsample == 1, "oracle restates the skip_decoding=True encode path only"
+        ref_y, ref_c = ref_frame
+        cur_y, cur_c = cur_frame
+        mv = self.compress_mv(ref_y, cur_y, dpb, stage_idx=stage_idx, q_index=q_index)
+        files = {"mv": encode_p_bytes(mv["bit_stream"], 0)}
+        luma = self.compress_one_stage(ref_y, cur_y, code_lt, mv["mv_hat"], False, [1, 1, pic_height, pic_width],
+                                       stage_idx, q_index)
+        files["H"] = luma["H_bytes"]
+        chroma = self.compress_one_stage(ref_c, cur_c, code_lt, mv["mv_hat"], True,
+                                         [1, 2, pic_height // 2, pic_width // 2], stage_idx, q_index)
+        files["Hc"] = chroma["H_bytes"]
+        if code_lt:
+            files["L"] = luma["L_bytes"]
+            files["Lc"] = chroma["L_bytes"]
+        if output_path is not None:
+            base = os.path.basename(output_path)
+            names = {"mv": output_path.replace(".bin", "_mv.bin"), "H": output_path,
+                     "Hc": output_path.replace(".bin", "_C_main.bin"),
+                     "L": output_path.replace(base, "0_main.bin"), "Lc": output_path.replace(base, "0_C_main.bin")}
+            for k, data in files.items():
+                with open(names[k], "wb") as f:
+                    f.write(data)
+        bits = {k: len(v) * 8.0 for k, v in files.items()}
+        return {
+            "L_t": luma["L_t_hat"] if code_lt else luma["L_t"],
+            "H_t": luma["H_t_hat"],
+            "L_tc": chroma["L_t_hat"] if code_lt else chroma["L_t"],
+            "H_tc": chroma["H_t_hat"],
+            "bit_H": bits["H"] + bits["Hc"],
+            "bit_L": bits["L"] + bits["Lc"] if code_lt else None,
+            "bit_Lc": bits["Lc"] if code_lt else None,
+            "bit_Hc": bits["Hc"],
+            "bit_ME": bits["mv"],
+            "mv_hat": mv["mv_hat"],
+            "dpb": {"mv_feature": mv["mv_feature"], "ref_mv_y": mv["mv_y_hat"]},
+            "files": files,
+            "traces": {"mv": mv["trace"], "H": luma["H_trace"], "Hc": chroma["H_trace"],
+                       "L": luma["L_trace"], "Lc": chroma["L_trace"]},
+        }
