@@ -82,6 +82,65 @@ int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, int W, float
 /* F.interpolate bilinear /2, align_corners=False, result divided by `div` (video_net.py:66-71; pMCTF_L.py:317,401) */
 int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H, int W, float div, void *stream);
 
+/* ---- elementwise / layout family -------------------------------------------------------------
+ * One strided kernel covers the reference's glue tensor ops (torch add/sub/mul/div, slicing, cat,
+ * chunk, permute, tile, clamp, round, leaky_relu).  Operands are 4-D views (n,c,h,w) given by element
+ * strides so[4]/sa[4]/sb[4] (HOST pointers to int64[4]; 0 = broadcast); b may be NULL.  cfast != 0
+ * iterates c fastest (NHWC outputs), else w fastest (planar outputs).  One IEEE rounding per written
+ * operation, never fused. */
+#define PMCTF_EW_COPY 0              /* a                                                        */
+#define PMCTF_EW_ADD 1               /* a + b            e.g. L = ref + inv, pMCTF_L.py:311       */
+#define PMCTF_EW_SUB 2               /* a - b            e.g. H = cur - pred, pMCTF_L.py:305      */
+#define PMCTF_EW_MUL 3               /* a * b                                                    */
+#define PMCTF_EW_DIV 4               /* a / b                                                    */
+#define PMCTF_EW_MULS 5              /* a * alpha        e.g. out * quant_step, video_net.py:143  */
+#define PMCTF_EW_DIVS 6              /* a / alpha        e.g. subband / QP, pWave.py:199          */
+#define PMCTF_EW_ADD_MULS 7          /* a + b*alpha                                              */
+#define PMCTF_EW_SUB_MULS 8          /* a - b*alpha                                              */
+#define PMCTF_EW_ADD_MULS_MULS 9     /* (a + b*alpha)*beta   predict/update_filter, wavelet_transform_temporal_mctf.py:27-45 */
+#define PMCTF_EW_CLAMP_MULS 10       /* clamp(a*alpha, -beta, beta)   quantize_subband, pWave.py:184-189 */
+#define PMCTF_EW_ROUND_CLAMP_MULS 11 /* round(clamp(a*alpha, -beta, beta))   pWave.py:408        */
+#define PMCTF_EW_ROUND 12            /* round half to even (torch.round)                         */
+#define PMCTF_EW_LEAKY 13            /* a > 0 ? a : a*alpha                                      */
+#define PMCTF_EW_ADD_MULS2 14        /* a + (b*alpha)*beta   lifting step, lifting_1d.py:108-111  */
+#define PMCTF_EW_SUB_MULS2 15        /* a - (b*alpha)*beta   inverse lifting, lifting_1d.py:155-160 */
+#define PMCTF_EW_ROUND_CLAMP 16      /* round(clamp(a, alpha, beta))   harness, test_pMCTF_flex.py:299-300 */
+#define PMCTF_EW_TANH 17             /* PM-F32 tanh(a)        lifting_1d.py:39                     */
+#define PMCTF_EW_LAST 17
+int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *a, const int64_t *sa, const float *b,
+                 const int64_t *sb, int N, int C, int H, int W, float alpha, float beta, int cfast, void *stream);
+
+/* SpyNet level input torch.cat([im1, warp(im2), flow_up]) (video_net.py:116-119) for Y-only frames
+ * (3 identical channels, pMCTF_L.py:453-454): planes im1[HW], warped[HW], flow_up[2][HW] -> NHWC [HW,8]. */
+int pmctf_spynet_pack8_f32(const float *im1, const float *warped, const float *flow_up, float *out, int H, int W,
+                           void *stream);
+/* ReflectionPad2d((0,0,1,1)) + 3x1 conv on NC single-channel planes (lifting_1d.py:98,105-106) */
+int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2, float bias,
+                         void *stream);
+/* nn.Upsample(scale_factor=2, mode="nearest") on NHWC (context_fusion_4step.py:50, long_context.py:50) */
+int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+/* nn.PixelShuffle(2) on NHWC [N,H,W,4C] -> [N,2H,2W,C], optional activation (video/layers.py:34-38,96-104) */
+int pmctf_pixel_shuffle2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, int act, float slope,
+                                  void *stream);
+/* ConvFFN3 gate: leaky(x1,0.1)+leaky(x2,0.01), x = [x1|x2] NHWC [P,2C] -> [P,C] (video/layers.py:163-167) */
+int pmctf_ffn3_mix_f32(const float *x, float *y, int64_t P, int C, void *stream);
+/* LSTM2D gates (long_context.py:20-33); xh = conv_in(x)+conv_hidden(h), NHWC [P,C]; cell [P,Ccell], Ccell in {1,C} */
+int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P, int C,
+                         int Ccell, void *stream);
+
+/* ---- quantisation + symbol hand-off --------------------------------
+ * sym/idx receive one full-size push (int16 symbol, int16 CDF row) in the reference's flattening order
+ * (NCHW), exactly what EntropyCoder.encode_with_indexes is given (entropy_models.py:37-40,269-278). */
+int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx, int N,
+                             int H, int W, int k, float log_scale_min, float log_scale_step, void *stream);
+int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx, int64_t total,
+                       float log_scale_min, float log_scale_step, void *stream);
+int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C, void *stream);
+int pmctf_mv_fourpart_step_f32(const float *y, const float *common, const float *sp, float *so_far, int16_t *sym,
+                               int16_t *idx, int H, int W, int t, float log_scale_min, float log_scale_step,
+                               void *stream);
+int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat, int64_t HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,368 @@
+// ew_ops.hip — elementwise / layout / quantisation kernels of the pMCTF encode path.
+// All are HBM-bound, one rounding per written operation (PM-F32), coalesced on the
+// output's unit-stride dimension.  Reference call sites are listed in include/pmctf_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pm_device_math.h"
+#include "../../include/pmctf_hip.h"
+
+namespace {
+
+inline int launch_ok() { return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH; }
+inline unsigned grid_for(long n, int bs = 256, unsigned cap = 16384) {
+    long b = (n + bs - 1) / bs;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+struct View { long s[4]; };  // element strides of the logical (n,c,h,w) index
+
+__device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha, float beta) {
+    switch (op) {
+    case PMCTF_EW_COPY: return a;
+    case PMCTF_EW_ADD: return a + b;
+    case PMCTF_EW_SUB: return a - b;
+    case PMCTF_EW_MUL: return a * b;
+    case PMCTF_EW_DIV: return a / b;
+    case PMCTF_EW_MULS: return a * alpha;
+    case PMCTF_EW_DIVS: return a / alpha;
+    case PMCTF_EW_ADD_MULS: return a + b * alpha;
+    case PMCTF_EW_SUB_MULS: return a - b * alpha;
+    case PMCTF_EW_ADD_MULS_MULS: return (a + b * alpha) * beta;
+    case PMCTF_EW_CLAMP_MULS: { float t = a * alpha; t = t < -beta ? -beta : t; return t > beta ? beta : t; }
+    case PMCTF_EW_ROUND_CLAMP_MULS: { float t = a * alpha; t = t < -beta ? -beta : t; t = t > beta ? beta : t; return __builtin_rintf(t); }
+    case PMCTF_EW_ROUND: return __builtin_rintf(a);
+    case PMCTF_EW_LEAKY: return a > 0.0f ? a : a * alpha;
+    case PMCTF_EW_ADD_MULS2: return a + (b * alpha) * beta;
+    case PMCTF_EW_SUB_MULS2: return a - (b * alpha) * beta;
+    case PMCTF_EW_TANH: return pm::tanhf_(a);
+    case PMCTF_EW_ROUND_CLAMP: { float t = a < alpha ? alpha : a; t = t > beta ? beta : t; return __builtin_rintf(t); }
+    default: return a;
+    }
+}
+
+template <bool CFAST>
+__global__ void ew_kernel(int op, float *out, View vo, const float *a, View va, const float *b, View vb, int N, int C,
+                          int H, int W, float alpha, float beta) {
+    const long total = (long)N * C * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        int n, c, h, w;
+        if (CFAST) { c = (int)(r % C); r /= C; w = (int)(r % W); r /= W; h = (int)(r % H); n = (int)(r / H); }
+        else { w = (int)(r % W); r /= W; h = (int)(r % H); r /= H; c = (int)(r % C); n = (int)(r / C); }
+        const float av = a[n * va.s[0] + c * va.s[1] + h * va.s[2] + w * va.s[3]];
+        const float bv = b ? b[n * vb.s[0] + c * vb.s[1] + h * vb.s[2] + w * vb.s[3]] : 0.0f;
+        out[n * vo.s[0] + c * vo.s[1] + h * vo.s[2] + w * vo.s[3]] = ew_apply(op, av, bv, alpha, beta);
+    }
+}
+
+// SpyNet level input: [im1 x3, warp x3, flow_up x2] -> NHWC 8 channels (video_net.py:116-119; the three image
+// channels are identical copies of Y, pMCTF_L.py:453-454)
+__global__ void spynet_pack8_kernel(const float *__restrict__ im1, const float *__restrict__ wrp,
+                                    const float *__restrict__ fu, float *out, long HW) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const float a = im1[p], b = wrp[p];
+        float4 lo = make_float4(a, a, a, b), hi = make_float4(b, b, fu[p], fu[HW + p]);
+        float4 *o = (float4 *)(out + p * 8);
+        o[0] = lo; o[1] = hi;
+    }
+}
+
+// reflectionPadSkip + 3x1 conv along H on single-channel planes (lifting_1d.py:98,105-106):
+// acc = bias; acc = fmaf(x[refl(y-1)], w0, acc); acc = fmaf(x[y], w1, acc); acc = fmaf(x[refl(y+1)], w2, acc)
+__global__ void lift_skip3_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float w0, float w1,
+                                  float w2, float bias) {
+    const long total = (long)NC * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int xw = (int)(idx % W);
+        long r = idx / W;
+        const int yy = (int)(r % H);
+        const long nc = r / H;
+        const int ym = yy == 0 ? 1 : yy - 1;
+        const int yp = yy == H - 1 ? H - 2 : yy + 1;
+        const float *pl = x + nc * H * W;
+        float acc = bias;
+        acc = __builtin_fmaf(pl[(long)ym * W + xw], w0, acc);
+        acc = __builtin_fmaf(pl[(long)yy * W + xw], w1, acc);
+        acc = __builtin_fmaf(pl[(long)yp * W + xw], w2, acc);
+        y[idx] = acc;
+    }
+}
+
+__global__ void nearest_up2_kernel(const float *__restrict__ x, float *y, int N, int H, int W, int C) {
+    const long total = (long)N * 2 * H * 2 * W * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long r = idx / C;
+        const int ox = (int)(r % (2 * W)); r /= 2 * W;
+        const int oy = (int)(r % (2 * H));
+        const int n = (int)(r / (2 * H));
+        y[idx] = x[(((long)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+
+// nn.PixelShuffle(2) on NHWC: out[n,2h+i,2w+j,c] = act(x[n,h,w,c*4+i*2+j])
+__global__ void pixel_shuffle2_kernel(const float *__restrict__ x, float *y, int N, int H, int W, int C, int act,
+                                      float slope) {
+    const long total = (long)N * 2 * H * 2 * W * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long r = idx / C;
+        const int ox = (int)(r % (2 * W)); r /= 2 * W;
+        const int oy = (int)(r % (2 * H));
+        const int n = (int)(r / (2 * H));
+        const float v = x[(((long)n * H + (oy >> 1)) * W + (ox >> 1)) * (4 * C) + c * 4 + (oy & 1) * 2 + (ox & 1)];
+        y[idx] = pm::apply_act(v, act, slope);
+    }
+}
+
+// ConvFFN3 gate (video/layers.py:163-167): out = leaky(x1, 0.1) + leaky(x2, 0.01), x = [x1 | x2] on channels
+__global__ void ffn3_mix_kernel(const float *__restrict__ x, float *y, long P, int C) {
+    const long total = P * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long p = idx / C;
+        const float x1 = x[p * 2 * C + c], x2 = x[p * 2 * C + C + c];
+        const float a = x1 > 0.0f ? x1 : x1 * 0.1f;
+        const float b = x2 > 0.0f ? x2 : x2 * 0.01f;
+        y[idx] = a + b;
+    }
+}
+
+// LSTM2D gates (long_context.py:20-33): f = sigmoid(xh); cell' = f*cell + f*tanh(xh); hidden' = f*tanh(cell')
+__global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__restrict__ cell, float *cell_out,
+                                  float *hid_out, long P, int C, int Cc) {
+    const long total = P * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long p = idx / C;
+        const float v = xh[idx];
+        const float g = pm::sigmoidf_(v);
+        const float ct = pm::tanhf_(v);
+        const float cprev = cell[p * Cc + (Cc == 1 ? 0 : c)];
+        const float t1 = g * cprev;
+        const float t2 = g * ct;
+        const float cn = t1 + t2;
+        cell_out[idx] = cn;
+        hid_out[idx] = g * pm::tanhf_(cn);
+    }
+}
+
+// GaussianEncoder.build_indexes (entropy_models.py:269-273) in PM-F32
+__device__ __forceinline__ int scale_index(float s, float lmin, float step) {
+    s = s < 1e-5f ? 1e-5f : s;   // torch.maximum(scales, 1e-5)
+    float v = (pm::logf_(s) - lmin) / step;
+    v = v < 0.0f ? 0.0f : v;
+    v = v > 255.0f ? 255.0f : v;
+    return (int)v;
+}
+__device__ __forceinline__ short sym16(float q) {  // symbols.clamp(-30000, 30000).to(int16), entropy_models.py:38
+    q = q < -30000.0f ? -30000.0f : q;
+    q = q > 30000.0f ? 30000.0f : q;
+    return (short)(int)q;
+}
+
+// One step of ContextFusionFourStep.forward(write=True) (context_fusion_4step.py:127-189) for parity class k.
+// x, so_far: planes [N,H,W]; params NHWC [N,H,W,2] = (scale, mean).  Writes this step's full-size push
+// (int16 symbol + int16 CDF row per element, NCHW order) and x_hat_so_far at the class-k positions.
+__global__ void fourstep_quant_kernel(const float *__restrict__ x, const float *__restrict__ params, float *so_far,
+                                      short *sym, short *idx, int N, int H, int W, int k, float lmin, float step) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xw = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        const int cls = (yy & 1) * 2 + (xw & 1);
+        if (cls == k) {
+            const float scale = params[i * 2], mean = params[i * 2 + 1];
+            const float res = x[i] - mean;
+            const float q = __builtin_rintf(res);
+            so_far[i] = q + mean;
+            sym[i] = sym16(q);
+            idx[i] = (short)scale_index(scale, lmin, step);
+        } else {
+            if (k == 0) so_far[i] = 0.0f;
+            sym[i] = 0;
+            idx[i] = 0;
+        }
+    }
+}
+
+// LL subband (pWave.py:408-418 with gaussian_model.py:59-63): ll is already round(clamp(ll*QP_ll));
+// res = ll - mean; sym = round(res); ll_hat = round(round(res) + mean)
+__global__ void ll_quant_kernel(const float *__restrict__ ll, const float *__restrict__ params, float *ll_hat,
+                                short *sym, short *idx, long total, float lmin, float step) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float scale = params[i * 2], mean = params[i * 2 + 1];
+        const float res = __builtin_rintf(ll[i]) - mean;
+        const float q = __builtin_rintf(res);
+        ll_hat[i] = __builtin_rintf(q + mean);
+        sym[i] = sym16(q);
+        idx[i] = (short)scale_index(scale, lmin, step);
+    }
+}
+
+// MV hyper latent: z_hat = round(z) (NHWC), push in NCHW order with CDF row = channel (entropy_models.py:180-193)
+__global__ void z_symbols_kernel(const float *__restrict__ z, float *z_hat, short *sym, short *idx, int HW, int C) {
+    const long total = (long)HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const float q = __builtin_rintf(z[i]);
+        z_hat[i] = q;
+        sym[(long)c * HW + p] = sym16(q);
+        idx[(long)c * HW + p] = (short)c;
+    }
+}
+
+// One step t of MVCoderQuad.forward_four_part_prior(write=True) (four_part_prior.py:89-208, enc_dec_quant).
+// y: NHWC [HW,64] latent; common: NHWC [HW,192] = (quant_step | scales | means); sp: NHWC [HW,128] spatial-prior
+// output of this step (8 chunks of 16: scales_0..3, means_0..3), unused for t == 0.  Channel group g=c/16 is
+// coded at the positions of parity class PERM[t][g].  so_far: NHWC [HW,64] (y_hat accumulated, un-dequantised).
+__constant__ int MV_PERM[4][4] = {{0, 1, 2, 3}, {3, 2, 1, 0}, {2, 3, 0, 1}, {1, 0, 3, 2}};
+__global__ void mv_fourpart_kernel(const float *__restrict__ y, const float *__restrict__ common,
+                                   const float *__restrict__ sp, float *so_far, short *sym, short *idx, int H, int W,
+                                   int t, float lmin, float step) {
+    const long HW = (long)H * W;
+    const long total = HW * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 63);
+        const long p = i >> 6;
+        const int xw = (int)(p % W), yy = (int)(p / W);
+        const int cls = (yy & 1) * 2 + (xw & 1);
+        const int g = c >> 4, cc = c & 15;
+        if (MV_PERM[t][g] == cls) {
+            float qs = common[p * 192 + c];
+            qs = qs > 0.5f ? qs : 0.5f;                    // LowerBound(quant_step, 0.5)
+            const float q_enc = 1.0f / qs;
+            float scale, mean;
+            if (t == 0) { scale = common[p * 192 + 64 + c]; mean = common[p * 192 + 128 + c]; }
+            else { scale = sp[p * 128 + g * 16 + cc]; mean = sp[p * 128 + 64 + g * 16 + cc]; }
+            const float ys = y[i] * q_enc;
+            const float q = __builtin_rintf(ys - mean);
+            so_far[i] = q + mean;
+            sym[(long)cc * HW + p] = sym16(q);
+            idx[(long)cc * HW + p] = (short)scale_index(scale, lmin, step);
+        } else if (t == 0) {
+            so_far[i] = 0.0f;
+        }
+    }
+}
+
+// y_hat = y_hat_so_far * q_dec (four_part_prior.py:193-194)
+__global__ void mv_dequant_kernel(const float *__restrict__ so_far, const float *__restrict__ common, float *y_hat,
+                                  long HW) {
+    const long total = HW * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 63);
+        const long p = i >> 6;
+        float qs = common[p * 192 + c];
+        qs = qs > 0.5f ? qs : 0.5f;
+        y_hat[i] = so_far[i] * qs;
+    }
+}
+
+}  // namespace
+
+extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *a, const int64_t *sa, const float *b,
+                            const int64_t *sb, int N, int C, int H, int W, float alpha, float beta, int cfast,
+                            void *stream) {
+    if (!out || !a || !so || !sa || N <= 0 || C <= 0 || H <= 0 || W <= 0 || op < 0 || op > PMCTF_EW_LAST)
+        return PMCTF_EINVAL;
+    View vo, va, vb;
+    for (int i = 0; i < 4; ++i) { vo.s[i] = so[i]; va.s[i] = sa[i]; vb.s[i] = (b && sb) ? sb[i] : 0; }
+    const long total = (long)N * C * H * W;
+    if (cfast)
+        hipLaunchKernelGGL(ew_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
+                           b, vb, N, C, H, W, alpha, beta);
+    else
+        hipLaunchKernelGGL(ew_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
+                           b, vb, N, C, H, W, alpha, beta);
+    return launch_ok();
+}
+
+extern "C" int pmctf_spynet_pack8_f32(const float *im1, const float *warped, const float *flow_up, float *out, int H,
+                                      int W, void *stream) {
+    if (!im1 || !warped || !flow_up || !out || H <= 0 || W <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(spynet_pack8_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, (hipStream_t)stream, im1, warped,
+                       flow_up, out, (long)H * W);
+    return launch_ok();
+}
+
+extern "C" int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2,
+                                    float bias, void *stream) {
+    if (!x || !y || NC <= 0 || H < 2 || W <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(lift_skip3_kernel, dim3(grid_for((long)NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC,
+                       H, W, w0, w1, w2, bias);
+    return launch_ok();
+}
+
+extern "C" int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, N, H, W, C);
+    return launch_ok();
+}
+
+extern "C" int pmctf_pixel_shuffle2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, int act, float slope,
+                                             void *stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, N, H, W, C, act, slope);
+    return launch_ok();
+}
+
+extern "C" int pmctf_ffn3_mix_f32(const float *x, float *y, int64_t P, int C, void *stream) {
+    if (!x || !y || P <= 0 || C <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(ffn3_mix_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)P, C);
+    return launch_ok();
+}
+
+extern "C" int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P,
+                                    int C, int Ccell, void *stream) {
+    if (!xh || !cell || !cell_out || !hid_out || P <= 0 || C <= 0 || (Ccell != 1 && Ccell != C)) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(lstm_gates_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, xh, cell, cell_out,
+                       hid_out, (long)P, C, Ccell);
+    return launch_ok();
+}
+
+extern "C" int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx,
+                                        int N, int H, int W, int k, float log_scale_min, float log_scale_step,
+                                        void *stream) {
+    if (!x || !params || !so_far || !sym || !idx || N <= 0 || H <= 0 || W <= 0 || k < 0 || k > 3) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(fourstep_quant_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                       params, so_far, sym, idx, N, H, W, k, log_scale_min, log_scale_step);
+    return launch_ok();
+}
+
+extern "C" int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx,
+                                  int64_t total, float log_scale_min, float log_scale_step, void *stream) {
+    if (!ll || !params || !ll_hat || !sym || !idx || total <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(ll_quant_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ll, params, ll_hat, sym,
+                       idx, (long)total, log_scale_min, log_scale_step);
+    return launch_ok();
+}
+
+extern "C" int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C,
+                                   void *stream) {
+    if (!z || !z_hat || !sym || !idx || HW <= 0 || C <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(z_symbols_kernel, dim3(grid_for((long)HW * C)), dim3(256), 0, (hipStream_t)stream, z, z_hat, sym,
+                       idx, HW, C);
+    return launch_ok();
+}
+
+extern "C" int pmctf_mv_fourpart_step_f32(const float *y, const float *common, const float *sp, float *so_far,
+                                          int16_t *sym, int16_t *idx, int H, int W, int t, float log_scale_min,
+                                          float log_scale_step, void *stream) {
+    if (!y || !common || !so_far || !sym || !idx || H <= 0 || W <= 0 || t < 0 || t > 3 || (t > 0 && !sp))
+        return PMCTF_EINVAL;
+    hipLaunchKernelGGL(mv_fourpart_kernel, dim3(grid_for((long)H * W * 64)), dim3(256), 0, (hipStream_t)stream, y, common,
+                       sp, so_far, sym, idx, H, W, t, log_scale_min, log_scale_step);
+    return launch_ok();
+}
+
+extern "C" int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat, int64_t HW, void *stream) {
+    if (!so_far || !common || !y_hat || HW <= 0) return PMCTF_EINVAL;
+    hipLaunchKernelGGL(mv_dequant_kernel, dim3(grid_for(HW * 64)), dim3(256), 0, (hipStream_t)stream, so_far, common,
+                       y_hat, (long)HW);
+    return launch_ok();
+}

@@ -1,0 +1,591 @@
+"""HipEngine — the pMCTF encode hot path on MI355X.
+
+Sequences the gfx950 kernels of libpmctf_hip.so (through pMCTF.hip.ops) for every function of
+SURVEY.md §8(a): SpyNet, flow warp, temporal predict/update lifting, the MV codec, the learned
+spatial DWT, the four-step context-fusion entropy model with its conv-LSTM context, the post-processing
+CNN and the symbol hand-off to the host range coder.  Python only allocates tensors and orders
+launches; no numeric torch op runs on this path.
+
+Data layout: single-channel planes are (N,1,H,W) dense; feature maps are NHWC (N,H,W,C) dense.
+Weights are packed once per prefix (first use) from the owning module's state_dict.
+Arithmetic follows the PM-F32 spec, which makes results bit-identical to the oracle's
+C restatement (oracle/, test infrastructure) and byte-identical bitstreams.
+"""
+import math
+import threading
+from concurrent.futures import ThreadPoolExecutor
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import ops
+from .ops import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, EW_ADD, EW_ADD_MULS2, EW_ADD_MULS_MULS, EW_CLAMP_MULS,
+                  EW_COPY, EW_DIVS, EW_MULS, EW_ROUND_CLAMP_MULS, EW_SUB, EW_SUB_MULS2, EW_TANH, as_nchw, ew)
+
+QP_NUM = 21
+SCALE_L = 1.149604398860241     # iWave1D scale_l / scale_h, lifting_1d.py:62,100-101
+SCALE_H = 0.869864451624781
+
+
+def get_curr_q(q_scale, q_index):
+    """pMCTF_L.py:195-209 / pWave.py:209-225 — host scalar arithmetic on the CPU copy of the parameter."""
+    min_q = q_scale[0:1]
+    max_q = q_scale[1:2]
+    step = (torch.log(max_q) - torch.log(min_q)) / (QP_NUM - 1)
+    return torch.exp(torch.log(min_q) + step * q_index)
+
+
+def get_rounded_q(q_scale):
+    """stream_helper.py:41-45"""
+    q_scale = np.clip(q_scale, 0.01, 655.)
+    q_index = int(np.round(q_scale * 100))
+    return q_index / 100, q_index
+
+
+class SymbolStream:
+    """Device-side int16 (symbol, CDF row) buffers of one bitstream, filled push by push in coding order."""
+
+    def __init__(self, total, device):
+        self.sym = torch.empty(total, dtype=torch.int16, device=device)
+        self.idx = torch.empty(total, dtype=torch.int16, device=device)
+        self.off = 0
+        self.total = total
+        self.segments = []          # (offset, count, table_name)
+
+    def take(self, n, table):
+        off = self.off
+        assert off + n <= self.total, "symbol stream overflow"
+        self.off += n
+        if self.segments and self.segments[-1][2] == table and self.segments[-1][0] + self.segments[-1][1] == off:
+            o, c, t = self.segments[-1]
+            self.segments[-1] = (o, c + n, t)
+        else:
+            self.segments.append((off, n, table))
+        return off
+
+    def to_host(self):
+        """Asynchronous D2H into pinned memory; returns (sym, idx, event)."""
+        assert self.off == self.total, (self.off, self.total)
+        hs = torch.empty(self.total, dtype=torch.int16, pin_memory=True)
+        hi = torch.empty(self.total, dtype=torch.int16, pin_memory=True)
+        hs.copy_(self.sym, non_blocking=True)
+        hi.copy_(self.idx, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return hs, hi, ev
+
+
+class RangeCoderPool:
+    """Host range coding overlapped with GPU work: one job = one bitstream file.  ctypes releases the GIL
+    inside libpmctf_rans.so, so streams are coded in parallel on worker threads."""
+
+    def __init__(self, workers=4):
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.local = threading.local()
+
+    def _encoder(self):
+        e = getattr(self.local, "enc", None)
+        if e is None:
+            e = _lib.rans().pmctf_rans_encoder_create(0, 1)
+            if not e:
+                raise RuntimeError("pmctf_rans_encoder_create failed")
+            self.local.enc = e
+        return e
+
+    def _run(self, hs, hi, ev, segments, tables, header, path, keep):
+        R = _lib.rans()
+        ev.synchronize()
+        enc = self._encoder()
+        _lib.check(R.pmctf_rans_encoder_reset(enc), "rans reset")
+        s_np, i_np = hs.numpy(), hi.numpy()
+        for off, cnt, tname in segments:
+            cdf, sizes, offsets = tables[tname]
+            _lib.check(R.pmctf_rans_encoder_encode_with_indexes(
+                enc, s_np[off:].ctypes.data, i_np[off:].ctypes.data, cnt, cdf.ctypes.data, cdf.shape[0], cdf.shape[1],
+                sizes.ctypes.data, offsets.ctypes.data), "rans encode_with_indexes")
+        _lib.check(R.pmctf_rans_encoder_flush(enc), "rans flush")
+        hdr = header(R.pmctf_rans_encoder_stream_size(enc))
+        if path is not None:
+            size = R.pmctf_rans_encoder_write_file(enc, hdr, len(hdr), path.encode())
+            if size < 0:
+                raise IOError(f"writing {path} failed ({size})")
+        else:
+            size = len(hdr) + R.pmctf_rans_encoder_stream_size(enc)
+        data = None
+        if keep:
+            n = R.pmctf_rans_encoder_stream_size(enc)
+            buf = np.empty(n, np.uint8)
+            _lib.check(R.pmctf_rans_encoder_get_encoded_stream(enc, buf.ctypes.data, n), "rans get stream")
+            data = hdr + buf.tobytes()
+        return size, data, (s_np, i_np) if keep else None
+
+    def submit(self, stream, tables, header, path, keep=False):
+        hs, hi, ev = stream.to_host()
+        return self.pool.submit(self._run, hs, hi, ev, list(stream.segments), tables, header, path, keep)
+
+
+class HipEngine:
+    def __init__(self, state_dict, num_me_stages, device, gaussian_tables, bit_est_tables, decomp_levels=4,
+                 coder_threads=4):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pMCTF HIP engine needs a GPU: the product path has no CPU fallback")
+        _lib.hip()
+        _lib.rans()
+        self.dev = torch.device(device)
+        self.num_me_stages = num_me_stages
+        self.L = decomp_levels
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in state_dict.items()}
+        for k in list(sd.keys()):                       # MaskedConv2d: weight *= mask (layers/layers.py:49-51)
+            if k.endswith(".mask"):
+                sd[k[:-5] + ".weight"] = sd[k[:-5] + ".weight"] * sd[k]
+        self.sd = sd
+        self._convs = {}
+        self._dw = {}
+        self._lin = {}
+        # entropy tables: name -> (cdf int32 [R,C], sizes int32 [R], offsets int32 [R]) host arrays
+        self.tables = {"gauss": tuple(np.ascontiguousarray(a, dtype=np.int32) for a in gaussian_tables["cdf_info"])}
+        for i, t in enumerate(bit_est_tables):
+            self.tables[f"z{i}"] = tuple(np.ascontiguousarray(a, dtype=np.int32) for a in t)
+        self.lmin = gaussian_tables["log_scale_min"]
+        self.lstep = gaussian_tables["log_scale_step"]
+        self.coder = RangeCoderPool(coder_threads)
+        self.keep_streams = False       # tests: keep bytes + symbol traces of each stream
+
+    # ------------------------------------------------------------------ packed layers
+    def conv(self, p, stride=1, padding=0):
+        key = (p, stride, padding)
+        c = self._convs.get(key)
+        if c is None:
+            c = ops.Conv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride, (padding, padding), self.dev)
+            self._convs[key] = c
+        return c
+
+    def dwconv(self, p):
+        c = self._dw.get(p)
+        if c is None:
+            c = ops.DepthwiseConv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), self.dev)
+            self._dw[p] = c
+        return c
+
+    def lin_tables(self, H, W):
+        """the cached linspace(-1,1,.) grids of video_net.py:33-40 (built once per shape, on the host)"""
+        t = self._lin.get((H, W))
+        if t is None:
+            t = (torch.linspace(-1.0, 1.0, W).to(self.dev), torch.linspace(-1.0, 1.0, H).to(self.dev))
+            self._lin[(H, W)] = t
+        return t
+
+    def warp(self, im, flow, sign=1.0):
+        lx, ly = self.lin_tables(im.shape[2], im.shape[3])
+        return ops.flow_warp(im, flow, lx, ly, sign)
+
+    # ------------------------------------------------------------------ a6 PredictUpdate (lifting_1d.py:36-49)
+    def predict_update(self, p, x):
+        """x: plane (N,1,H,W) -> plane"""
+        N, _, H, W = x.shape
+        xin = x.view(N, H, W, 1)
+        c1 = self.conv(p + ".conv1", 1, 1)(xin)
+        t = as_nchw_ew(EW_TANH, c1)
+        t = self.conv(p + ".conv2", 1, 1)(t, act=ACT_TANH)
+        t = self.conv(p + ".conv3", 1, 1)(t, res1=c1)
+        out = self.conv(p + ".conv4", 1, 1)(t)
+        return out.view(N, 1, H, W)
+
+    def predict_filter(self, stage, x):
+        """wavelet_transform_temporal_mctf.py:27-35: (x + 0.1*P(x)) * (1/sqrt2)"""
+        pu = self.predict_update(f"temporal_filtering.{stage}.P_t", x)
+        return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 1 / math.sqrt(2))
+
+    def update_filter(self, stage, x):
+        pu = self.predict_update(f"temporal_filtering.{stage}.U_t", x)
+        return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 0.5)
+
+    # ------------------------------------------------------------------ a5/a7 (pMCTF_L.py:297-330)
+    def forward_MCTF(self, ref, cur, mv_hat, stage_idx=0):
+        me = min(self.num_me_stages - 1, stage_idx)
+        pred = self.predict_filter(me, self.warp(ref, mv_hat))
+        H_t = ew(EW_SUB, cur, pred)
+        inv = self.update_filter(me, self.warp(H_t, mv_hat, -1.0))
+        L_t = ew(EW_ADD, ref, inv)
+        return L_t, H_t, pred, inv
+
+    def inverse_MCTF(self, L_t, H_t, mv_hat, downscale=False, stage_idx=0):
+        me = min(self.num_me_stages - 1, stage_idx)
+        if downscale:
+            mv_hat = ops.bilinear_down2(mv_hat, 2.0)
+        inv = self.update_filter(me, self.warp(H_t, mv_hat, -1.0))
+        ref = ew(EW_SUB, L_t, inv)
+        pred = self.predict_filter(me, self.warp(ref, mv_hat))
+        cur = ew(EW_ADD, H_t, pred)
+        return ref, cur
+
+    # ------------------------------------------------------------------ a3 SpyNet (video_net.py:93-121)
+    def spynet(self, cur_y, ref_y, levels=6):
+        im1 = [ew(EW_DIVS, cur_y, alpha=255.0)]
+        im2 = [ew(EW_DIVS, ref_y, alpha=255.0)]
+        for l in range(levels - 1):
+            im1.append(ops.avgpool2(im1[l]))
+            im2.append(ops.avgpool2(im2[l]))
+        hs, ws = im2[levels - 1].shape[2] // 2, im2[levels - 1].shape[3] // 2
+        flow = torch.zeros((1, 2, hs, ws), dtype=torch.float32, device=self.dev)
+        for level in range(levels):
+            flow_up = ops.bilinear_up2(flow, 2.0)
+            i = levels - 1 - level
+            warped = self.warp(im2[i], flow_up)
+            x = ops.spynet_pack8(im1[i], warped, flow_up)
+            p = f"optic_flow.moduleBasic.{level}"
+            for k in (1, 2, 3, 4):
+                x = self.conv(f"{p}.conv{k}", 1, 3)(x, act=ACT_RELU)
+            y5 = self.conv(f"{p}.conv5", 1, 3)(x)
+            flow = ew(EW_ADD, flow_up, as_nchw(y5))
+        return flow
+
+    # ------------------------------------------------------------------ video/layers.py blocks (NHWC)
+    def res_block_stride(self, p, x, stride=2):
+        out = self.conv(p + ".conv1", stride, 1)(x, act=ACT_LEAKY, slope=0.01)
+        identity = self.conv(p + ".downsample", stride, 0)(x) if stride != 1 else x
+        return self.conv(p + ".conv2", 1, 1)(out, act=ACT_LEAKY, slope=0.1, res1=identity)
+
+    def res_block_up(self, p, x):
+        out = ops.pixel_shuffle2(self.conv(p + ".subpel_conv.0")(x), ACT_LEAKY, 0.01)
+        identity = ops.pixel_shuffle2(self.conv(p + ".upsample.0")(x))
+        return self.conv(p + ".conv", 1, 1)(out, act=ACT_LEAKY, slope=0.1, res1=identity)
+
+    def depth_conv(self, p, x):
+        identity = self.conv(p + ".adaptor")(x) if (p + ".adaptor.weight") in self.sd else x
+        t = self.conv(p + ".conv1.0")(x, act=ACT_LEAKY, slope=0.01)
+        t = self.dwconv(p + ".depth_conv")(t)
+        return self.conv(p + ".conv2")(t, res1=identity)
+
+    def depth_conv_block(self, p, x):
+        x = self.depth_conv(p + ".block.0", x)
+        t = self.conv(p + ".block.1.conv.0")(x, act=ACT_LEAKY, slope=0.1)
+        return self.conv(p + ".block.1.conv.2")(t, act=ACT_LEAKY, slope=0.1, res1=x)
+
+    def depth_conv_block4(self, p, x):
+        x = self.depth_conv(p + ".block.0", x)
+        t = ops.ffn3_mix(self.conv(p + ".block.1.conv")(x))
+        return self.conv(p + ".block.1.conv_out")(t, res1=x)
+
+    def cat_channels(self, a, b):
+        N, H, W, Ca = a.shape
+        Cb = b.shape[3]
+        out = ops.empty_nhwc(N, H, W, Ca + Cb, self.dev)
+        ew(EW_COPY, as_nchw(a), out=as_nchw(out)[:, :Ca])
+        ew(EW_COPY, as_nchw(b), out=as_nchw(out)[:, Ca:])
+        return out
+
+    # ------------------------------------------------------------------ MV codec (video_net.py:124-191)
+    def mv_enc(self, s, est_mv, context, q_enc):
+        p = f"mv_encoder.{s}"
+        N, _, H, W = est_mv.shape
+        x = ops.empty_nhwc(N, H, W, 2, self.dev)
+        ew(EW_COPY, est_mv, out=as_nchw(x))
+        out = self.res_block_stride(p + ".enc_1.0", x)
+        out = self.depth_conv_block(p + ".enc_1.1", out)
+        out = as_nhwc_ew(EW_MULS, out, alpha=q_enc)
+        out = self.res_block_stride(p + ".enc_2", out)
+        if context is None:
+            out = self.depth_conv_block(p + ".adaptor_0", out)
+        else:
+            out = self.depth_conv_block(p + ".adaptor_1", self.cat_channels(out, context))
+        out = self.res_block_stride(p + ".enc_3.0", out)
+        out = self.depth_conv_block(p + ".enc_3.1", out)
+        return self.conv(p + ".enc_3.2", 2, 1)(out)
+
+    def mv_dec(self, s, y_hat, q_dec):
+        p = f"mv_decoder.{s}"
+        f = self.depth_conv_block(p + ".dec_1.0", y_hat)
+        f = self.res_block_up(p + ".dec_1.1", f)
+        f = self.depth_conv_block(p + ".dec_1.2", f)
+        f = self.res_block_up(p + ".dec_1.3", f)
+        feature = self.depth_conv_block(p + ".dec_1.4", f)
+        out = self.res_block_up(p + ".dec_2", feature)
+        out = as_nhwc_ew(EW_MULS, out, alpha=q_dec)
+        out = self.depth_conv_block(p + ".dec_3.0", out)
+        mv = ops.pixel_shuffle2(self.conv(p + ".dec_3.1.0")(out))       # (1,H,W,2)
+        N, H, W, _ = mv.shape
+        mv_planar = ops.empty_planar(N, 2, H, W, self.dev)
+        ew(EW_COPY, as_nchw(mv), out=mv_planar)
+        return mv_planar, feature
+
+    def mv_hyper_enc(self, s, x):
+        p = f"mv_hyper_prior_encoder.{s}"
+        x = self.depth_conv_block4(p + ".0", x)
+        x = self.conv(p + ".1", 2, 1)(x, act=ACT_LEAKY, slope=0.01)
+        return self.conv(p + ".3", 2, 1)(x)
+
+    def mv_hyper_dec(self, s, x):
+        p = f"mv_hyper_prior_decoder.{s}"
+        x = self.res_block_up(p + ".0", x)
+        x = self.res_block_up(p + ".1", x)
+        return self.depth_conv_block4(p + ".2", x)
+
+    def mv_prior_param_decoder(self, z_hat, ref_mv_y, s):
+        params = self.mv_hyper_dec(s, z_hat)
+        if ref_mv_y is None:
+            params = self.depth_conv_block(f"mv_y_prior_fusion_adaptor_0.{s}", params)
+        else:
+            params = self.depth_conv_block(f"mv_y_prior_fusion_adaptor_1.{s}", self.cat_channels(params, ref_mv_y))
+        params = self.depth_conv_block(f"mv_y_prior_fusion.{s}.0", params)
+        return self.depth_conv_block(f"mv_y_prior_fusion.{s}.1", params)
+
+    def get_mv_y_q(self, q_index, s):
+        enc, _ = get_rounded_q(get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index).numpy())
+        dec, _ = get_rounded_q(get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index).numpy())
+        return enc, dec
+
+    def to_nhwc_input(self, t):
+        """dpb tensors come back from the caller as logical NCHW; accept channels-last or planar storage."""
+        if t is None:
+            return None
+        v = t.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+        N, Cc, H, W = t.shape
+        out = ops.empty_nhwc(N, H, W, Cc, self.dev)
+        ew(EW_COPY, t, out=as_nchw(out))
+        return out
+
+    # ------------------------------------------------------------------ a2 compress_mv (pMCTF_L.py:448-495)
+    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0):
+        s = min(self.num_me_stages - 1, stage_idx)
+        q_enc, q_dec = self.get_mv_y_q(q_index, s)
+        est_mv = self.spynet(cur_y, ref_y)
+        mv_y = self.mv_enc(s, est_mv, self.to_nhwc_input(dpb["mv_feature"]), q_enc)
+        mv_z = self.mv_hyper_enc(s, mv_y)
+        _, hy, wy, _ = mv_y.shape
+        _, hz, wz, cz = mv_z.shape
+        stream = SymbolStream(hz * wz * cz + 4 * 16 * hy * wy, self.dev)
+        z_hat = ops.z_symbols(mv_z, stream.sym, stream.idx, stream.take(hz * wz * cz, f"z{s}"))
+        common = self.mv_prior_param_decoder(z_hat, self.to_nhwc_input(dpb["ref_mv_y"]), s)
+        so_far = torch.empty_like(mv_y)
+        sp = None
+        for t in range(4):
+            if t > 0:
+                x = self.conv(f"mv_y_spatial_prior_adaptor_{t}.{s}")(self.cat_channels(so_far, common))
+                for i in range(3):
+                    x = self.depth_conv_block(f"mv_y_spatial_prior.{s}.{i}", x)
+                sp = x
+            ops.mv_fourpart_step(mv_y, common, sp, so_far, stream.sym, stream.idx, stream.take(16 * hy * wy, "gauss"),
+                                 t, self.lmin, self.lstep)
+        mv_y_hat = ops.mv_dequant(so_far, common)
+        mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        return {"stream": stream, "mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat,
+                "est_mv": est_mv, "mv_y": mv_y, "z_hat": z_hat, "common": common}
+
+    # ------------------------------------------------------------------ a10 learned lifting DWT
+    def lift_branch(self, wt, conv_name, pu_name, x):
+        """skip + 0.1 * 256 * PU(skip/256)   (lifting_1d.py:105-110)"""
+        w = self.sd[f"{wt}.{conv_name}.weight"].reshape(-1)
+        b = self.sd[f"{wt}.{conv_name}.bias"].reshape(-1)
+        skip = ops.lift_skip3(x, w.tolist(), float(b[0]))
+        pu = self.predict_update(f"{wt}.{pu_name}", ew(EW_DIVS, skip, alpha=256.0))
+        return ew(EW_ADD_MULS2, skip, pu, 256.0, 0.1)
+
+    def forward_lift(self, wt, x):
+        """iWave1D.forward_lift along H (lifting_1d.py:103-145); x plane (N,1,H,W) -> l, h (N,1,H/2,W)"""
+        x_e = ew(EW_COPY, x[:, :, ::2, :])
+        x_o = ew(EW_COPY, x[:, :, 1::2, :])
+        x_o = ew(EW_ADD, x_o, self.lift_branch(wt, "conv_P1", "P_1", x_e))
+        x_e = ew(EW_ADD, x_e, self.lift_branch(wt, "conv_U1", "U_1", x_o))
+        x_o = ew(EW_ADD, x_o, self.lift_branch(wt, "conv_P2", "P_2", x_e))
+        x_e = ew(EW_ADD, x_e, self.lift_branch(wt, "conv_U2", "U_2", x_o))
+        return ew(EW_MULS, x_e, alpha=SCALE_L), ew(EW_MULS, x_o, alpha=SCALE_H)
+
+    def backward_lift(self, wt, l, h):
+        """iWave1D.backward_lift (lifting_1d.py:147-189)"""
+        l = ew(EW_DIVS, l, alpha=SCALE_L)
+        h = ew(EW_DIVS, h, alpha=SCALE_H)
+        l = ew(EW_SUB, l, self.lift_branch(wt, "conv_U2", "U_2", h))
+        h = ew(EW_SUB, h, self.lift_branch(wt, "conv_P2", "P_2", l))
+        l = ew(EW_SUB, l, self.lift_branch(wt, "conv_U1", "U_1", h))
+        h = ew(EW_SUB, h, self.lift_branch(wt, "conv_P1", "P_1", l))
+        N, _, H2, W = l.shape
+        x = ops.empty_planar(N, 1, 2 * H2, W, self.dev)
+        ew(EW_COPY, l, out=x[:, :, ::2, :])
+        ew(EW_COPY, h, out=x[:, :, 1::2, :])
+        return x
+
+    def transpose(self, x):
+        return ew(EW_COPY, x.permute(0, 1, 3, 2))
+
+    def forward_lift_2d(self, coder, x):
+        """LiftingScheme2D.forward_lift_2d (wavelet_transform.py:25-42)"""
+        wt = f"{coder}.wavelet_transform.lift_h"
+        l, h = self.forward_lift(wt, x)
+        ll, lh = self.forward_lift(wt, self.transpose(l))
+        hl, hh = self.forward_lift(wt, self.transpose(h))
+        return {k: self.transpose(v) for k, v in (("ll", ll), ("lh", lh), ("hl", hl), ("hh", hh))}
+
+    def backward_lift_2d(self, coder, sb):
+        wt = f"{coder}.wavelet_transform.lift_h"
+        l = self.transpose(self.backward_lift(wt, self.transpose(sb["ll"]), self.transpose(sb["lh"])))
+        h = self.transpose(self.backward_lift(wt, self.transpose(sb["hl"]), self.transpose(sb["hh"])))
+        return self.backward_lift(wt, l, h)
+
+    # ------------------------------------------------------------------ a11 LL parameters (context_fusion.py:100-128)
+    def context_fusion_ll(self, coder, ll):
+        p = f"{coder}.context_fusion.{self.L - 1}.ll"
+        N, _, H, W = ll.shape
+        x = self.conv(p + ".maskedConv1", 1, 1)(ll.view(N, H, W, 1))
+        conv1 = x
+        for i in range(2):
+            q = f"{p}.residualBlocks.{i}"
+            o = self.conv(q + ".conv1", 1, 1)(x, act=ACT_LEAKY, slope=0.2)
+            if i == 1:
+                x = self.conv(q + ".conv2", 1, 1)(o, res1=x, res2=conv1)      # (o + x) + conv1
+            else:
+                x = self.conv(q + ".conv2", 1, 1)(o, res1=x)
+        x = self.conv(p + ".maskedConv2", 1, 1)(x, act=ACT_LEAKY, slope=0.2)
+        x = self.conv(p + ".convs.0")(x, act=ACT_LEAKY, slope=0.2)
+        x = self.conv(p + ".convs.1")(x, act=ACT_LEAKY, slope=0.2)
+        return self.conv(p + ".convs.2")(x)
+
+    # ------------------------------------------------------------------ a12 four-step context fusion
+    def context_residual(self, p, x, res2=None):
+        o = self.conv(p + ".conv1", 1, 1)(x, act=ACT_LEAKY, slope=0.2)
+        return self.conv(p + ".conv2", 1, 1)(o, res1=x, res2=res2)
+
+    def fusion_compress(self, p, x, ctx, prev, stream):
+        """ContextFusionFourStep.forward(write=True) (context_fusion_4step.py:139-191).
+        x: plane (N,1,h,w); ctx: NHWC (N,h,w,1); prev: plane of the previous level's subband or None."""
+        N, _, H, W = x.shape
+        if prev is not None:
+            up = ops.nearest_up2(prev.view(N, H // 2, W // 2, 1))
+            prevc = self.conv(p + ".lower_level_subband.1", 1, 1)(up)
+            ctx = self.cat_channels(ctx, prevc)
+        c = self.conv(p + ".conv1_context", 1, 1)(ctx)
+        c = self.context_residual(p + ".y_hierarchical_prior_enc.0", c)
+        c = self.context_residual(p + ".y_hierarchical_prior_enc.1", c)
+        params = self.depth_conv_block(p + ".y_hierarchical_prior_out", c)
+        so_far = torch.empty_like(x)
+        n = N * H * W
+        ops.fourstep_quant(x, params, so_far, stream.sym, stream.idx, stream.take(n, "gauss"), 0, self.lmin, self.lstep)
+        for step in (1, 2, 3):
+            t = self.conv(f"{p}.y_spatial_prior_{step}.0", 1, 1)(so_far.view(N, H, W, 1))
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t, res2=c)      # (.. + x) + context
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.0", t)
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
+            params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
+            ops.fourstep_quant(x, params, so_far, stream.sym, stream.idx, stream.take(n, "gauss"), step, self.lmin,
+                               self.lstep)
+        return so_far
+
+    # ------------------------------------------------------------------ a13 conv-LSTM context (long_context.py)
+    def lstm(self, p, x, state):
+        a = self.conv(p + ".conv_in", 1, 1)(x)
+        xh = self.conv(p + ".conv_hidden", 1, 1)(state[0], res1=a)
+        hid, cell = ops.lstm_gates(xh, state[1])
+        return [hid, cell]
+
+    def ctx_init(self, N, H, W):
+        z = lambda c: torch.zeros((N, H, W, c), dtype=torch.float32, device=self.dev)
+        self.l3 = [z(3), z(1)]          # init_sequential quirk: 1-channel cell state (long_context.py:163-164)
+        self.l1 = [z(32), z(32)]
+        self.l2 = [z(32), z(32)]
+
+    def ctx_upsample(self, p, x):
+        return self.conv(p + ".conv", 1, 1)(ops.nearest_up2(x))
+
+    def ctx_forward_one_subband(self, coder, subband, name, lvl):
+        p = f"{coder}.context_prediction"
+        N, _, H, W = subband.shape
+        self.l1 = self.lstm(p + ".LSTM1", subband.view(N, H, W, 1), self.l1)
+        self.l2 = self.lstm(p + ".LSTM2", self.l1[0], self.l2)
+        self.l3 = self.lstm(p + ".LSTM3", self.l2[0], self.l3)
+        if name == "hh" and lvl > 0:
+            for st, nm in ((self.l1, "1"), (self.l2, "2"), (self.l3, "3")):
+                st[0] = self.ctx_upsample(f"{p}.deconv_h{nm}.{lvl - 1}", st[0])
+                st[1] = self.ctx_upsample(f"{p}.deconv_c{nm}.{lvl - 1}", st[1])
+        return self.l3[0]
+
+    # ------------------------------------------------------------------ a14 PostProcess (postprocessing.py:35-44)
+    def post_process(self, coder, x, in_div=1.0, out_mul=1.0):
+        """returns (x/in_div + net(x/in_div)) * out_mul"""
+        p = f"{coder}.dequantModule"
+        N, _, H, W = x.shape
+        xs = ew(EW_DIVS, x, alpha=in_div) if in_div != 1.0 else x
+        tmp = self.conv(p + ".conv1", 1, 1)(xs.view(N, H, W, 1))
+        conv1 = tmp
+        for i in range(6):
+            q = f"{p}.resBlocks.{i}"
+            o = self.conv(q + ".conv1", 1, 1)(tmp, act=ACT_LEAKY, slope=0.2)
+            tmp = self.conv(q + ".conv2", 1, 1)(o, res1=tmp)
+        tmp = self.conv(p + ".conv2", 1, 1)(tmp, res1=conv1)
+        tmp = self.conv(p + ".conv3", 1, 1)(tmp)
+        return ew(EW_ADD_MULS_MULS, xs, tmp.view(N, 1, H, W), 1.0, out_mul)
+
+    # ------------------------------------------------------------------ a9 pWave.compress (pWave.py:381-463)
+    def pwave_symbol_count(self, N, H, W):
+        n = N * (H >> self.L) * (W >> self.L)
+        for lvl in range(self.L):
+            n += 3 * 4 * N * (H >> (lvl + 1)) * (W >> (lvl + 1))
+        return n
+
+    def pwave_compress(self, coder, x, q_index, qp_scale=None):
+        """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream)."""
+        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+        if qp_scale is not None:
+            q_scale = q_scale * qp_scale
+            q_scale_ll = q_scale_ll * qp_scale
+        q_scale, q_scale_ll = float(q_scale), float(q_scale_ll)
+        N, _, H, W = x.shape
+        clip = 8192.0
+        y = {}
+        ll = x
+        for lvl in range(self.L):
+            y[lvl] = self.forward_lift_2d(coder, ll)
+            ll = y[lvl]["ll"]
+        stream = SymbolStream(self.pwave_symbol_count(N, H, W), self.dev)
+        hat = {lvl: {} for lvl in range(self.L)}
+        llq = ew(EW_ROUND_CLAMP_MULS, ll, alpha=q_scale_ll, beta=clip)
+        params = self.context_fusion_ll(coder, llq)
+        ll_hat = ops.ll_quant(llq, params, stream.sym, stream.idx, stream.take(llq.numel(), "gauss"), self.lmin,
+                              self.lstep)
+        hat[self.L - 1]["ll"] = ll_hat
+        self.ctx_init(N, ll.shape[2], ll.shape[3])
+        context = self.ctx_forward_one_subband(coder, ll_hat, "ll", self.L - 1)
+        for lvl in range(self.L - 1, -1, -1):
+            for sidx, sb in enumerate(("lh", "hl", "hh")):
+                h, w = context.shape[1], context.shape[2]
+                ctx = ops.empty_nhwc(N, h, w, 1, self.dev)
+                ew(EW_COPY, as_nchw(context)[:, sidx:sidx + 1], out=as_nchw(ctx))
+                prev = hat[lvl + 1][sb] if lvl < self.L - 1 else None
+                s_curr = ew(EW_CLAMP_MULS, y[lvl][sb], alpha=q_scale, beta=clip)
+                s_hat = self.fusion_compress(f"{coder}.context_fusion.{lvl}.{sb}", s_curr, ctx, prev, stream)
+                hat[lvl][sb] = s_hat
+                context = self.ctx_forward_one_subband(coder, s_hat, sb, lvl)
+        out = None
+        rec_ll = ew(EW_DIVS, hat[self.L - 1]["ll"], alpha=q_scale_ll)
+        for lvl in range(self.L - 1, -1, -1):
+            sbs = {"ll": rec_ll}
+            for sb in ("lh", "hl", "hh"):
+                sbs[sb] = ew(EW_DIVS, hat[lvl][sb], alpha=q_scale)
+            out = self.backward_lift_2d(coder, sbs)
+            rec_ll = out
+        x_hat = self.post_process(coder, out, 256.0, 256.0)
+        return x_hat, stream
+
+    # ------------------------------------------------------------------ a8 compress_one_stage (pMCTF_L.py:398-420)
+    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0):
+        if ischroma:
+            mv_hat = ops.bilinear_down2(mv_hat, 2.0)
+        L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        H_hat, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale)
+        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": H_hat, "H_stream": h_stream, "L_t_hat": None, "L_stream": None}
+        if code_lt:
+            out["L_t_hat"], out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index)
+        return out
+
+
+def as_nchw_ew(op, t_nhwc, alpha=0.0, beta=0.0):
+    """elementwise op on an NHWC tensor, result NHWC (N,H,W,C)"""
+    return ew(op, as_nchw(t_nhwc), alpha=alpha, beta=beta).permute(0, 2, 3, 1)
+
+
+as_nhwc_ew = as_nchw_ew

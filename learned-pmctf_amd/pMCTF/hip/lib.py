@@ -27,11 +27,60 @@ _SIGS = {
     "pmctf_avgpool2_f32": (ci, [vp, vp, ci, ci, ci, vp]),
     "pmctf_bilinear_up2_f32": (ci, [vp, vp, ci, ci, ci, cf, vp]),
     "pmctf_bilinear_down2_f32": (ci, [vp, vp, ci, ci, ci, cf, vp]),
+    "pmctf_ew_f32": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp]),
+    "pmctf_spynet_pack8_f32": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+    "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, vp]),
+    "pmctf_nearest_up2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "pmctf_pixel_shuffle2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, vp]),
+    "pmctf_ffn3_mix_f32": (ci, [vp, vp, i64, ci, vp]),
+    "pmctf_lstm_gates_f32": (ci, [vp, vp, vp, vp, i64, ci, ci, vp]),
+    "pmctf_fourstep_quant_f32": (ci, [vp] * 5 + [ci, ci, ci, ci, cf, cf, vp]),
+    "pmctf_ll_quant_f32": (ci, [vp] * 5 + [i64, cf, cf, vp]),
+    "pmctf_z_symbols_f32": (ci, [vp] * 4 + [ci, ci, vp]),
+    "pmctf_mv_fourpart_step_f32": (ci, [vp] * 6 + [ci, ci, ci, cf, cf, vp]),
+    "pmctf_mv_dequant_f32": (ci, [vp, vp, vp, i64, vp]),
 }
+
+
+_RANS_SIGS = {
+    "pmctf_rans_encoder_create": (vp, [ci, ci]),
+    "pmctf_rans_encoder_destroy": (None, [vp]),
+    "pmctf_rans_encoder_reset": (ci, [vp]),
+    "pmctf_rans_encoder_encode_with_indexes": (ci, [vp, vp, vp, i64, vp, ci, ci, vp, vp]),
+    "pmctf_rans_encoder_flush": (ci, [vp]),
+    "pmctf_rans_encoder_stream_size": (i64, [vp]),
+    "pmctf_rans_encoder_get_encoded_stream": (ci, [vp, vp, i64]),
+    "pmctf_rans_encoder_write_file": (i64, [vp, vp, i64, C.c_char_p]),
+    "pmctf_rans_decoder_create": (vp, [ci]),
+    "pmctf_rans_decoder_destroy": (None, [vp]),
+    "pmctf_rans_decoder_set_stream": (ci, [vp, vp, i64]),
+    "pmctf_rans_decoder_decode_stream": (ci, [vp, vp, i64, vp, ci, ci, vp, vp, vp]),
+    "pmctf_pmf_to_quantized_cdf": (ci, [vp, ci, ci, vp]),
+}
+_rans = None
 
 
 class NativeLibraryError(RuntimeError):
     pass
+
+
+def rans():
+    """Load libpmctf_rans.so (host range coder, C ABI include/pmctf_rans.h)."""
+    global _rans
+    if _rans is None:
+        if not os.path.exists(RANS_SO):
+            raise NativeLibraryError(
+                f"{RANS_SO} not found: build it with `make -C {PKG_ROOT}` (or __graft_entry__.build())")
+        L = C.CDLL(RANS_SO)
+        for name, (res, args) in _RANS_SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _rans = L
+    return _rans
+
+
+def rans_exported_symbols():
+    return list(_RANS_SIGS.keys())
 
 
 def hip():

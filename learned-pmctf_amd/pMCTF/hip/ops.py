@@ -130,3 +130,144 @@ def bilinear_down2(x, div=1.0):
     _lib.check(_lib.hip().pmctf_bilinear_down2_f32(_p(x), _p(y), N * Cc, H, W, float(div), _stream()),
                "bilinear_down2")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise / layout family (pmctf_ew_f32): operands are logical (N,C,H,W) views with any strides
+EW_COPY, EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_MULS, EW_DIVS, EW_ADD_MULS, EW_SUB_MULS, EW_ADD_MULS_MULS, \
+    EW_CLAMP_MULS, EW_ROUND_CLAMP_MULS, EW_ROUND, EW_LEAKY, EW_ADD_MULS2, EW_SUB_MULS2, EW_ROUND_CLAMP, EW_TANH = range(18)
+
+_I64x4 = C.c_int64 * 4
+
+
+def _raw(t):
+    assert t.is_cuda and t.dtype == torch.float32
+    return C.c_void_p(t.data_ptr())
+
+
+def as_nchw(t_nhwc):
+    """NHWC storage (N,H,W,C) -> logical NCHW view (no copy)."""
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+def as_nhwc(t_nchw):
+    """logical NCHW view whose storage is channels-last dense -> (N,H,W,C) dense tensor (no copy)."""
+    v = t_nchw.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise ValueError("tensor is not channels-last dense")
+    return v
+
+
+def empty_planar(n, c, h, w, device):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=device)
+
+
+def empty_nhwc(n, h, w, c, device):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=device)
+
+
+def ew(op, a, b=None, alpha=0.0, beta=0.0, out=None):
+    """out = op(a, b) over logical (N,C,H,W) views (b may be broadcast with stride 0 via expand)."""
+    N, Cc, H, W = a.shape
+    if out is None:
+        if Cc > 1 and a.stride(1) == 1:
+            out = as_nchw(empty_nhwc(N, H, W, Cc, a.device))
+        else:
+            out = empty_planar(N, Cc, H, W, a.device)
+    assert tuple(out.shape) == (N, Cc, H, W), (tuple(out.shape), (N, Cc, H, W))
+    if b is not None and tuple(b.shape) != (N, Cc, H, W):
+        b = b.expand(N, Cc, H, W)
+    so, sa = _I64x4(*out.stride()), _I64x4(*a.stride())
+    sb = _I64x4(*b.stride()) if b is not None else None
+    cfast = 1 if (Cc > 1 and out.stride(1) == 1) else 0
+    _lib.check(_lib.hip().pmctf_ew_f32(int(op), _raw(out), so, _raw(a), sa, None if b is None else _raw(b), sb,
+                                       N, Cc, H, W, float(alpha), float(beta), cfast, _stream()), "ew")
+    return out
+
+
+def spynet_pack8(im1, warped, flow_up):
+    _, _, H, W = im1.shape
+    out = empty_nhwc(1, H, W, 8, im1.device)
+    _lib.check(_lib.hip().pmctf_spynet_pack8_f32(_p(im1), _p(warped), _p(flow_up), _p(out), H, W, _stream()),
+               "spynet_pack8")
+    return out
+
+
+def lift_skip3(x, w3, bias):
+    N, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.hip().pmctf_lift_skip3_f32(_p(x), _p(y), N * Cc, H, W, float(w3[0]), float(w3[1]), float(w3[2]),
+                                               float(bias), _stream()), "lift_skip3")
+    return y
+
+
+def nearest_up2(x):
+    N, H, W, Cc = x.shape
+    y = empty_nhwc(N, 2 * H, 2 * W, Cc, x.device)
+    _lib.check(_lib.hip().pmctf_nearest_up2_nhwc_f32(_p(x), _p(y), N, H, W, Cc, _stream()), "nearest_up2")
+    return y
+
+
+def pixel_shuffle2(x, act=ACT_NONE, slope=0.0):
+    N, H, W, C4 = x.shape
+    assert C4 % 4 == 0
+    y = empty_nhwc(N, 2 * H, 2 * W, C4 // 4, x.device)
+    _lib.check(_lib.hip().pmctf_pixel_shuffle2_nhwc_f32(_p(x), _p(y), N, H, W, C4 // 4, int(act), float(slope),
+                                                        _stream()), "pixel_shuffle2")
+    return y
+
+
+def ffn3_mix(x):
+    N, H, W, C2 = x.shape
+    y = empty_nhwc(N, H, W, C2 // 2, x.device)
+    _lib.check(_lib.hip().pmctf_ffn3_mix_f32(_p(x), _p(y), N * H * W, C2 // 2, _stream()), "ffn3_mix")
+    return y
+
+
+def lstm_gates(xh, cell):
+    N, H, W, Cc = xh.shape
+    cell_out, hid_out = torch.empty_like(xh), torch.empty_like(xh)
+    _lib.check(_lib.hip().pmctf_lstm_gates_f32(_p(xh), _p(cell), _p(cell_out), _p(hid_out), N * H * W, Cc,
+                                               cell.shape[3], _stream()), "lstm_gates")
+    return hid_out, cell_out
+
+
+def _p16(t, off):
+    assert t.is_cuda and t.dtype == torch.int16 and t.is_contiguous()
+    return C.c_void_p(t.data_ptr() + 2 * off)
+
+
+def fourstep_quant(x, params, so_far, sym, idx, off, k, lmin, lstep):
+    N, _, H, W = x.shape
+    _lib.check(_lib.hip().pmctf_fourstep_quant_f32(_p(x), _p(params), _p(so_far), _p16(sym, off), _p16(idx, off),
+                                                   N, H, W, k, float(lmin), float(lstep), _stream()), "fourstep_quant")
+
+
+def ll_quant(ll, params, sym, idx, off, lmin, lstep):
+    ll_hat = torch.empty_like(ll)
+    _lib.check(_lib.hip().pmctf_ll_quant_f32(_p(ll), _p(params), _p(ll_hat), _p16(sym, off), _p16(idx, off),
+                                             ll.numel(), float(lmin), float(lstep), _stream()), "ll_quant")
+    return ll_hat
+
+
+def z_symbols(z, sym, idx, off):
+    N, H, W, Cc = z.shape
+    z_hat = torch.empty_like(z)
+    _lib.check(_lib.hip().pmctf_z_symbols_f32(_p(z), _p(z_hat), _p16(sym, off), _p16(idx, off), H * W, Cc, _stream()),
+               "z_symbols")
+    return z_hat
+
+
+def mv_fourpart_step(y, common, sp, so_far, sym, idx, off, t, lmin, lstep):
+    N, H, W, Cc = y.shape
+    assert N == 1 and Cc == 64
+    _lib.check(_lib.hip().pmctf_mv_fourpart_step_f32(_p(y), _p(common), _p(sp), _p(so_far), _p16(sym, off),
+                                                     _p16(idx, off), H, W, t, float(lmin), float(lstep), _stream()),
+               "mv_fourpart_step")
+
+
+def mv_dequant(so_far, common):
+    y_hat = torch.empty_like(so_far)
+    _lib.check(_lib.hip().pmctf_mv_dequant_f32(_p(so_far), _p(common), _p(y_hat), so_far.shape[1] * so_far.shape[2],
+                                               _stream()), "mv_dequant")
+    return y_hat

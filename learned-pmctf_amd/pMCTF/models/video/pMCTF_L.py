@@ -1,0 +1,194 @@
+"""pMCTF — variable-rate learned wavelet video coder (MCTF), MI355X-native encode path.
+
+Drop-in for pMCTF.models.video.pMCTF_L.pMCTF of the reference (pMCTF/models/video/pMCTF_L.py): same
+constructor, same parameter tree (load_state_dict(strict=True) of a reference checkpoint), same
+`update`, `encode_one_stage`, `inverse_MCTF`, `get_qp_num`, `num_me_stages`, so that
+test_pMCTF_flex.py runs unchanged.  All tensor arithmetic of the encode path runs in hand-written
+gfx950 kernels (pMCTF.hip.engine.HipEngine -> libpmctf_hip.so); the range coder is libpmctf_rans.so
+on host threads.  There is no CPU fallback: without a GPU and the built libraries the calls raise.
+
+Implemented: the write-stream encode branch with skip_decoding=True (pMCTF_L.py:553-637) and
+inverse_MCTF.  Not implemented in this round (raise NotImplementedError): the estimate-only branch
+(output_path=None; broken in the reference itself), skip_decoding=False (real decoder),
+me_downsample > 1, training forward.
+"""
+import os
+import os.path as osp
+import time
+
+import torch
+from torch import nn
+
+from pMCTF.entropy_models.entropy_models import BitEstimator
+from pMCTF.entropy_models.gaussian_model import CompressionModel
+from pMCTF.hip.engine import HipEngine
+from pMCTF.layers.modules import (DepthConvBlock, ME_Spynet, MvDec, MvEnc, TemporalLifting, get_hyper_dec_model,
+                                  get_hyper_enc_model)
+from pMCTF.models.pWave import pWave
+from pMCTF.utils.stream_helper import image_header, mv_header
+
+
+class MVCoderQuad(nn.Module):
+    """four-part MV latent coder (pMCTF/layers/video/four_part_prior.py) — parameter-free; the arithmetic is the
+    pmctf_mv_fourpart_step_f32 kernel."""
+
+    def __init__(self, enc_dec_quant=False):
+        super().__init__()
+        self.enc_dec_quant = enc_dec_quant
+
+
+class pMCTF(nn.Module):
+    def __init__(self, bitdepth=8, decomp_levels=4, lossy=True, two_stage_me=True, num_me_stages=2, quant_stage=True,
+                 **kwargs):
+        super().__init__()
+        self.bitdepth = bitdepth
+        self.dynamic_range = 2 ** bitdepth - 1
+        self.lossy = lossy
+        self.lp_coder = pWave(bitdepth, decomp_levels, lossy)
+        self.hp_coder = pWave(bitdepth, decomp_levels, lossy)
+        self.mse = nn.MSELoss(reduction="mean")
+        channel_mv, channel_N, channel_M = 64, 64, 32
+        self.channel_mv, self.channel_N, self.channel_M = channel_mv, channel_N, channel_M
+        self.optic_flow = ME_Spynet(L=6)
+        S = range(num_me_stages)
+        self.mv_encoder = nn.ModuleList([MvEnc(2, channel_mv) for _ in S])
+        self.mv_decoder = nn.ModuleList([MvDec(2, channel_mv) for _ in S])
+        self.mv_hyper_prior_encoder = nn.ModuleList([get_hyper_enc_model(channel_N, channel_mv) for _ in S])
+        self.mv_hyper_prior_decoder = nn.ModuleList([get_hyper_dec_model(channel_N, channel_mv) for _ in S])
+        self.mv_y_prior_fusion_adaptor_0 = nn.ModuleList([DepthConvBlock(channel_mv, channel_mv * 2) for _ in S])
+        self.mv_y_prior_fusion_adaptor_1 = nn.ModuleList([DepthConvBlock(channel_mv * 2, channel_mv * 2) for _ in S])
+        self.mv_y_prior_fusion = nn.ModuleList([nn.Sequential(DepthConvBlock(channel_mv * 2, channel_mv * 3),
+                                                              DepthConvBlock(channel_mv * 3, channel_mv * 3))
+                                                for _ in S])
+        self.mv_y_spatial_prior = nn.ModuleList([nn.Sequential(DepthConvBlock(channel_mv * 3, channel_mv * 3),
+                                                               DepthConvBlock(channel_mv * 3, channel_mv * 3),
+                                                               DepthConvBlock(channel_mv * 3, channel_mv * 2))
+                                                 for _ in S])
+        for k in (1, 2, 3):
+            setattr(self, f"mv_y_spatial_prior_adaptor_{k}",
+                    nn.ModuleList([nn.Conv2d(channel_mv * 4, channel_mv * 3, 1) for _ in S]))
+        self.mv_y_q_scale_enc = nn.ParameterList([nn.Parameter(torch.ones((2, 1, 1, 1))) for _ in S])
+        self.mv_y_q_scale_dec = nn.ParameterList([nn.Parameter(torch.ones((2, 1, 1, 1))) for _ in S])
+        self.mv_bit_est = nn.ModuleList([BitEstimator(channel_mv) for _ in S])
+        self.em = CompressionModel(y_distribution="laplace")
+        self.mv_coder = MVCoderQuad(enc_dec_quant=True)
+        self.temporal_filtering = nn.ModuleList([TemporalLifting() for _ in S])
+        self.quant_stage = quant_stage
+        if self.quant_stage:
+            self.hp_q_scale = nn.ParameterList([nn.Parameter(torch.ones((2, 1, 1, 1))) for _ in S])
+        self.two_stage_me = two_stage_me
+        self.num_me_stages = num_me_stages
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def get_qp_num():
+        return 21
+
+    def update(self, force=False):
+        """Build the CDF tables and the range coder (pMCTF_L.py:441-446), then pack weights for the GPU."""
+        self.em.update(force)
+        for i in range(self.num_me_stages):
+            self.mv_bit_est[i].update(force, entropy_coder=self.em.entropy_coder)
+        self.lp_coder.update(force)
+        self.hp_coder.update(force)
+        if force:
+            self._engine = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def engine(self):
+        if self._engine is None:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("pMCTF (MI355X build) encodes on the GPU only: move the model to 'cuda' "
+                                   "(test_pMCTF_flex.py --cuda 1); there is no CPU path")
+            ge = self.em.gaussian_encoder
+            if ge.get_cdf_info()[0] is None:
+                raise RuntimeError("call update(force=True) before encoding")
+            g = {"cdf_info": ge.get_cdf_info(), "log_scale_min": ge.log_scale_min, "log_scale_step": ge.log_scale_step}
+            z = [self.mv_bit_est[i].get_cdf_info() for i in range(self.num_me_stages)]
+            self._engine = HipEngine(self.state_dict(), self.num_me_stages, dev, g, z)
+        return self._engine
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def inverse_MCTF(self, L_t, H_t, mv_hat, downscale=False, stage_idx=0):
+        """pMCTF_L.py:314-330"""
+        c = lambda t: t.contiguous()
+        return self.engine().inverse_MCTF(c(L_t), c(H_t), c(mv_hat), downscale=downscale, stage_idx=stage_idx)
+
+    @torch.no_grad()
+    def forward_MCTF(self, ref_frame, cur_frame, mv_hat, stage_idx=0):
+        """pMCTF_L.py:297-312"""
+        c = lambda t: t.contiguous()
+        return self.engine().forward_MCTF(c(ref_frame), c(cur_frame), c(mv_hat), stage_idx)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("estimate-mode / training forward is outside the encode hot path of this build")
+
+    forward_one_stage = forward
+
+    @torch.no_grad()
+    def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
+                         psize=128, skip_decoding=False, stage_idx=0, q_index=0, me_downsample=1):
+        """Write-stream branch of pMCTF_L.py:525-637 for one frame pair."""
+        if output_path is None:
+            raise NotImplementedError("estimate-only branch (output_path=None) is not part of this build "
+                                      "(it raises KeyError in the reference as well)")
+        if not skip_decoding:
+            raise NotImplementedError("real decoding (skip_decoding=False) is the next scope item; "
+                                      "run with --skip_decoding 1")
+        if me_downsample != 1:
+            raise NotImplementedError("me_downsample > 1")
+        eng = self.engine()
+        ref_y, ref_chroma = ref_frame
+        cur_y, cur_chroma = cur_frame
+        dev = ref_y.device
+        c = lambda t: t.to(dev).contiguous()
+        start = time.time()
+        keep = eng.keep_streams
+        mv_out = output_path.replace(".bin", "_mv.bin")
+        mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index)
+        jobs = {"mv": eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0), mv_out, keep)}
+        mv_hat = mv["mv_hat"]
+        base = osp.basename(output_path)
+        luma = eng.compress_one_stage(c(ref_y), c(cur_y), code_lt, mv_hat, False, stage_idx, q_index)
+        jobs["H"] = eng.coder.submit(luma["H_stream"], eng.tables,
+                                     lambda n: image_header(pic_height, pic_width, 1, n), output_path, keep)
+        if code_lt:
+            jobs["L"] = eng.coder.submit(luma["L_stream"], eng.tables,
+                                         lambda n: image_header(pic_height, pic_width, 1, n),
+                                         output_path.replace(base, "0_main.bin"), keep)
+        file_name_c = output_path.replace(".bin", "_C_main.bin")
+        chroma = eng.compress_one_stage(c(ref_chroma), c(cur_chroma), code_lt, mv_hat, True, stage_idx, q_index)
+        jobs["Hc"] = eng.coder.submit(chroma["H_stream"], eng.tables,
+                                      lambda n: image_header(pic_height // 2, pic_width // 2, 2, n), file_name_c, keep)
+        if code_lt:
+            jobs["Lc"] = eng.coder.submit(chroma["L_stream"], eng.tables,
+                                          lambda n: image_header(pic_height // 2, pic_width // 2, 2, n),
+                                          output_path.replace(base, "0_C_main.bin"), keep)
+        done = {k: j.result() for k, j in jobs.items()}
+        encoding_time = time.time() - start
+        bits = {k: v[0] * 8.0 for k, v in done.items()}
+        result = {
+            "L_t": luma["L_t_hat"] if code_lt else luma["L_t"],
+            "H_t": luma["H_t_hat"],
+            "L_tc": chroma["L_t_hat"] if code_lt else chroma["L_t"],
+            "H_tc": chroma["H_t_hat"],
+            "bit_H": bits["H"] + bits["Hc"],
+            "bit_L": bits["L"] + bits["Lc"] if code_lt else None,
+            "bit_Lc": bits["Lc"] if code_lt else None,
+            "bit_Hc": bits["Hc"],
+            "bit_ME": bits["mv"],
+            "mv_hat": mv_hat,
+            "dpb": {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)},
+            "decoding_time": 0,
+            "encoding_time": encoding_time,
+        }
+        if keep:
+            result["files"] = {k: v[1] for k, v in done.items()}
+            result["traces"] = {k: v[2] for k, v in done.items()}
+        return result

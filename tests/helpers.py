@@ -1,0 +1,49 @@
+"""Shared test helpers: synthetic model/inputs for oracle and product."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name="reference_128x128.npz"):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def product_model(num_me_stages=1, device="cuda"):
+    """pMCTF (HIP product) with the deterministic synthetic weights, ready to encode."""
+    import pmctf_synth
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    net = pMCTF(num_me_stages=num_me_stages).eval()
+    sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(device)
+    net.update(force=True)
+    return net, sd
+
+
+def synth_sd_cpu(num_me_stages=1):
+    """The same synthetic state_dict built without touching the GPU (masks from the container modules)."""
+    import pmctf_synth
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    net = pMCTF(num_me_stages=num_me_stages)
+    return pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
+
+
+def frames(width, height, n, device="cpu", seed=1234):
+    import pmctf_synth
+    f8 = pmctf_synth.synth_yuv420(width, height, n, seed=seed)
+    return [list(pmctf_synth.frames_to_tensors(f, device=device)) for f in f8]
+
+
+def assert_same(a, b, what):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    neq = a != b
+    if neq.any():
+        i = tuple(np.argwhere(neq)[0])
+        raise AssertionError(f"{what}: {int(neq.sum())}/{a.size} elements differ; first at {i}: {a[i]!r} vs {b[i]!r}; "
+                             f"max abs diff {np.abs(a.astype(np.float64) - b.astype(np.float64)).max():.3e}")

@@ -1,0 +1,120 @@
+"""HIP product (through the drop-in pMCTF API) vs the oracle's PM-F32 restatement: bit-exact tensors, identical
+symbol streams and identical bitstream bytes; and vs the fixtures generated from the real reference."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_same, frames, golden, product_model
+
+pytestmark = pytest.mark.gpu
+
+W = H = 128
+
+
+@pytest.fixture(scope="module")
+def setup(cuda):
+    from pmctf_oracle.model import Oracle
+    net, sd = product_model(1)
+    net.engine().keep_streams = True
+    orc = Oracle(sd, 1, "cdef")
+    return net, orc
+
+
+def test_loaded_native_libraries(setup):
+    import ctypes, os
+    from pMCTF.hip import lib
+    maps = open("/proc/self/maps").read()
+    assert "libpmctf_hip.so" in maps and "libpmctf_rans.so" in maps
+
+
+def test_mctf_bitexact(setup):
+    import pmctf_synth
+    net, orc = setup
+    fr = frames(W, H, 2)
+    (Y0, C0), (Y1, C1) = fr
+    flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, H, W), 3.0))
+    L, Ht, pred, inv = net.forward_MCTF(Y0.cuda(), Y1.cuda(), flow.cuda())
+    oL, oH, opred, oinv = orc.forward_MCTF(Y0, Y1, flow)
+    assert_same(pred, opred, "pred"); assert_same(Ht, oH, "H_t"); assert_same(inv, oinv, "inv"); assert_same(L, oL, "L_t")
+    r, c = net.inverse_MCTF(L, Ht, flow.cuda())
+    orr, oc = orc.inverse_MCTF(oL, oH, flow)
+    assert_same(r, orr, "inverse ref"); assert_same(c, oc, "inverse cur")
+    # chroma: batch of two planes, motion = down2(mv)/2
+    rc, cc = net.inverse_MCTF(C0.cuda(), C1.cuda(), flow.cuda(), downscale=True)
+    orc_, occ = orc.inverse_MCTF(C0, C1, flow, downscale=True)
+    assert_same(rc, orc_, "chroma inverse ref"); assert_same(cc, occ, "chroma inverse cur")
+    g = golden()
+    assert np.abs(Ht.cpu().numpy() - g["unit.mctf.H"]).max() < 1e-3      # vs the real reference (fp noise only)
+
+
+def test_spynet_bitexact(setup):
+    net, orc = setup
+    (Y0, _), (Y1, _) = frames(W, H, 2)
+    est = net.engine().spynet(Y1.cuda(), Y0.cuda())
+    oest = orc.spynet(Y1.tile((1, 3, 1, 1)) / 255, Y0.tile((1, 3, 1, 1)) / 255)
+    assert_same(est, oest, "spynet flow")
+    assert np.abs(est.cpu().numpy() - golden()["unit.spynet"]).max() < 1e-5
+
+
+def test_dwt_postprocess_bitexact(setup):
+    net, orc = setup
+    eng = net.engine()
+    g = golden()
+    Hg = torch.from_numpy(g["unit.mctf.H"])
+    sb = eng.forward_lift_2d("hp_coder", Hg.cuda())
+    osb = orc.forward_lift_2d("hp_coder", Hg)
+    for k in ("ll", "lh", "hl", "hh"):
+        assert_same(sb[k], osb[k].contiguous(), f"dwt {k}")
+    rec = eng.backward_lift_2d("hp_coder", sb)
+    assert_same(rec, orc.backward_lift_2d("hp_coder", osb), "idwt")
+    pp = eng.post_process("hp_coder", Hg.cuda(), 256.0, 1.0)
+    assert_same(pp, orc.post_process("hp_coder", Hg / 256.0), "postprocess")
+
+
+def test_pwave_compress_stream_identical(setup):
+    from pmctf_oracle.model import get_curr_q
+    net, orc = setup
+    eng = net.engine()
+    g = golden()
+    Hg = torch.from_numpy(g["unit.mctf.H"])
+    qp = get_curr_q(orc.sd["hp_q_scale.0"], 3)
+    x_hat, stream = eng.pwave_compress("hp_coder", Hg.cuda(), 3, qp)
+    ox, odata, otrace = orc.pwave_compress("hp_coder", Hg, [1, 1, H, W], 3, qp)
+    from pMCTF.utils.stream_helper import image_header
+    size, data, (sym, idx) = eng.coder.submit(stream, eng.tables, lambda n: image_header(H, W, 1, n), None, True).result()
+    osym = np.concatenate([t[0] for t in otrace]); oidx = np.concatenate([t[1] for t in otrace])
+    assert_same(sym, osym, "symbols"); assert_same(idx, oidx, "cdf rows")
+    assert data == odata, "bitstream bytes differ"
+    assert_same(x_hat, ox, "x_hat")
+    # vs the real reference: identical file at this size, reconstruction within fp noise
+    assert data == g["pwave.file"].tobytes()
+    assert np.abs(x_hat.cpu().numpy() - g["pwave.x_hat"]).max() < 2e-3
+
+
+def test_gop4_files_bits_psnr(setup):
+    import pmctf_gop
+    net, orc = setup
+    fr = frames(W, H, 4)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    with tempfile.TemporaryDirectory() as td, tempfile.TemporaryDirectory() as td2:
+        enc = pmctf_gop.encode_gop(net, frd, H, W, 3, td)
+        oenc = pmctf_gop.encode_gop(orc, fr, H, W, 3, td2)
+        for i, (r, o) in enumerate(zip(enc["results"], oenc["results"])):
+            for k in o["files"]:
+                assert r["files"][k] == o["files"][k], f"pair {i} file {k} differs"
+            assert_same(r["mv_hat"], o["mv_hat"], f"pair {i} mv_hat")
+            assert_same(r["H_t"], o["H_t"], f"pair {i} H_t")
+            assert_same(r["L_t"], o["L_t"], f"pair {i} L_t")
+            assert_same(r["H_tc"], o["H_tc"], f"pair {i} H_tc")
+        assert enc["bits"] == oenc["bits"]
+        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+        orec = pmctf_gop.decode_gop(orc, oenc["frames_coded"])
+        for i in range(4):
+            assert_same(rec[i][0], orec[i][0], f"rec {i} luma"); assert_same(rec[i][1], orec[i][1], f"rec {i} chroma")
+        ps = pmctf_gop.gop_psnr(rec, frd, H, W)
+    g = golden()
+    # the fixtures come from the real reference: bpp bit-exact (file sizes), PSNR within 1e-4 dB
+    assert enc["bits"] == list(g["gop.bits"])
+    assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
