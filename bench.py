@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — encoded 1080p frames/s of the pMCTF temporal-decomposition encode path on MI355X.
+
+One "step" = one full GOP-16 encode of 1920x1080 4:2:0 frames at q_index=3 through the drop-in API
+(pMCTF.encode_one_stage for 15 pairs + the final L frame; bitstreams written by the host range
+coder), inputs already resident in HBM.  N GPUs encode N independent GOPs (closed GOPs are
+independent units: no data-path collective; weak scaling).  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
+
+import torch  # noqa: E402
+
+
+def cpu_baseline(width, height, gop):
+    """The oracle's restatement with the ATen CPU ops the reference itself calls ("port"), timed on a bounded
+    sample: one H pair and one H+L pair at 256x448 (BASELINE config 2 size), scaled by padded pixel count
+    to the 1080p GOP (work is linear in pixels)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pmctf_synth
+    from pmctf_oracle.model import Oracle
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    w, h = 448, 256
+    net = pMCTF(num_me_stages=1)
+    sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
+    orc = Oracle(sd, 1, "torch")
+    fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(w, h, 2)]
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with torch.no_grad():
+        t0 = time.time()
+        r = orc.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=w, pic_height=h, q_index=3)
+        t_h = time.time() - t0
+        t0 = time.time()
+        orc.encode_one_stage(fr[0], fr[1], True, r["dpb"], pic_width=w, pic_height=h, q_index=3)
+        t_hl = time.time() - t0
+    ph, pw = -(-h // 128) * 128, -(-w // 128) * 128
+    PH, PW = -(-height // 128) * 128, -(-width // 128) * 128
+    scale = (PH * PW) / (ph * pw)
+    t_gop = ((gop - 2) * t_h + t_hl) * scale
+    return {"value": gop / t_gop, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (ATen CPU ops, as the reference's CPU path) on one H pair ({t_h:.1f} s) and one H+L "
+                      f"pair ({t_hl:.1f} s) at {w}x{h}, scaled x{scale:.1f} by padded pixels to {gop - 2}*t_H + t_HL"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--gop", type=int, default=16)
+    ap.add_argument("--q_index", type=int, default=3)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import pmctf_gop
+    import pmctf_synth
+    from pMCTF.hip import ops
+    from pMCTF.models.video.pMCTF_L import pMCTF
+
+    stages = 1
+    while 2 ** stages < args.gop:
+        stages += 1
+    net = pMCTF(num_me_stages=min(4, stages)).eval()
+    net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to(dev)
+    net.update(force=True)
+
+    W, H = args.width, args.height
+    # every rank codes its own GOP (different frames of the synthetic sequence)
+    f8 = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234 + rank)
+    frames = [list(pmctf_synth.frames_to_tensors(f, device=dev)) for f in f8]
+    PH, PW = frames[0][0].shape[2], frames[0][0].shape[3]
+    sub_h, sub_w = PH // 2, PW // 2
+
+    def dominant(conv, x):   # ContextResidual 3x3 112->112 on a level-0 luma subband
+        return (not conv.small) and conv.Cin == 112 and conv.Cout == 112 and conv.KH == 3 and \
+            x.shape[0] == 1 and x.shape[1] == sub_h and x.shape[2] == sub_w
+
+    tmp = tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_")
+    last = {}
+
+    def step():
+        enc = pmctf_gop.encode_gop(net, frames, H, W, args.q_index, tmp)
+        last["enc"] = enc
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        sync()
+        probe = {"match": dominant, "events": []}
+        ops.CONV_PROBE = probe
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ops.CONV_PROBE = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = args.gop * args.steps * world
+    value = frames_total / elapsed
+    # dominant-kernel roofline from the live HIP events
+    durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in probe["events"]]
+    flops = probe["events"][0][2] if probe["events"] else 0.0
+    avg = sum(durs) / len(durs) if durs else float("nan")
+    achieved = flops / avg / 1e12 if durs else float("nan")
+    peak = 157.3
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<7,4,2> (3x3 112->112, f32 MFMA 16x16x4)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "launches": len(durs), "avg_launch_ms": avg * 1e3, "flops_per_launch": flops, "traffic": None}
+
+    if rank == 0:
+        enc = last["enc"]
+        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+        ps = pmctf_gop.gop_psnr(rec, frames, H, W)
+        out = {
+            "metric": "encoded 1080p frames/sec (GOP=16, q_index=3)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} 4:2:0 GOP-{args.gop} q_index={args.q_index} full pMCTF encode "
+                                   f"(write_stream, skip_decoding), num_me_stages={net.num_me_stages}",
+                       "frames_per_step": args.gop, "parallelism": f"gop-dp{world}",
+                       "weights": "deterministic synthetic (pmctf_synth seed 0)"},
+            "roofline": roofline,
+            "bpp": sum(enc["bits"]) / (args.gop * W * H),
+            "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, args.gop)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,11 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pm_device_math.h"
+#include "launch.h"
 #include "../../include/pmctf_hip.h"
 
 namespace {
 
-inline int launch_ok() { return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH; }
+inline int launch_ok() { return pm_launch_status(); }
 inline unsigned nblocks(long n, int bs = 256) {
     long b = (n + bs - 1) / bs;
     return (unsigned)(b < 1 ? 1 : b);
@@ -204,7 +205,7 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
     const long total = (long)N * Ho * Wo * Cout;
     unsigned g = nblocks(total);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(g), dim3(256), smem, (hipStream_t)stream, x, w, bias, res1, res2, y,
+    PM_LAUNCH(conv_smallcin_kernel, dim3(g), dim3(256), smem, (hipStream_t)stream, x, w, bias, res1, res2, y,
                        N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo, act, slope);
     return launch_ok();
 }
@@ -214,7 +215,7 @@ extern "C" int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const flo
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !(K & 1)) return PMCTF_EINVAL;
     unsigned g = nblocks((long)N * H * W * C);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(dwconv_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C, K);
+    PM_LAUNCH(dwconv_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C, K);
     return launch_ok();
 }
 
@@ -224,7 +225,7 @@ extern "C" int pmctf_flow_warp_f32(const float *im, const float *flow, const flo
         return PMCTF_EINVAL;
     unsigned g = nblocks((long)N * H * W);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(flow_warp_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, im, flow, lin_x, lin_y, out, N, C,
+    PM_LAUNCH(flow_warp_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, im, flow, lin_x, lin_y, out, N, C,
                        H, W, flowN, flow_sign);
     return launch_ok();
 }
@@ -233,7 +234,7 @@ extern "C" int pmctf_avgpool2_f32(const float *x, float *y, int NC, int H, int W
     if (!x || !y || NC <= 0 || H < 2 || W < 2) return PMCTF_EINVAL;
     unsigned g = nblocks((long)NC * (H / 2) * (W / 2));
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(avgpool2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W);
+    PM_LAUNCH(avgpool2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W);
     return launch_ok();
 }
 
@@ -241,7 +242,7 @@ extern "C" int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, i
     if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return PMCTF_EINVAL;
     unsigned g = nblocks((long)NC * H * W * 4);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(bilinear_up2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, scale);
+    PM_LAUNCH(bilinear_up2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, scale);
     return launch_ok();
 }
 
@@ -249,6 +250,6 @@ extern "C" int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H,
     if (!x || !y || NC <= 0 || H < 2 || W < 2) return PMCTF_EINVAL;
     unsigned g = nblocks((long)NC * (H / 2) * (W / 2));
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(bilinear_down2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, div);
+    PM_LAUNCH(bilinear_down2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, div);
     return launch_ok();
 }

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "pm_device_math.h"
+#include "launch.h"
 #include "../../include/pmctf_hip.h"
 
 namespace {
@@ -180,8 +181,8 @@ int launch(const ConvArgs &a, int MB, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
-    return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH;
+    PM_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
+    return pm_launch_status();
 }
 
 template <int MT>

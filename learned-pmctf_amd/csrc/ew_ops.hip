@@ -4,11 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pm_device_math.h"
+#include "launch.h"
 #include "../../include/pmctf_hip.h"
 
 namespace {
 
-inline int launch_ok() { return hipGetLastError() == hipSuccess ? PMCTF_OK : PMCTF_ELAUNCH; }
+inline int launch_ok() { return pm_launch_status(); }
 inline unsigned grid_for(long n, int bs = 256, unsigned cap = 16384) {
     long b = (n + bs - 1) / bs;
     if (b < 1) b = 1;
@@ -272,10 +273,10 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
     for (int i = 0; i < 4; ++i) { vo.s[i] = so[i]; va.s[i] = sa[i]; vb.s[i] = (b && sb) ? sb[i] : 0; }
     const long total = (long)N * C * H * W;
     if (cfast)
-        hipLaunchKernelGGL(ew_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
+        PM_LAUNCH(ew_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
                            b, vb, N, C, H, W, alpha, beta);
     else
-        hipLaunchKernelGGL(ew_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
+        PM_LAUNCH(ew_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
                            b, vb, N, C, H, W, alpha, beta);
     return launch_ok();
 }
@@ -283,7 +284,7 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
 extern "C" int pmctf_spynet_pack8_f32(const float *im1, const float *warped, const float *flow_up, float *out, int H,
                                       int W, void *stream) {
     if (!im1 || !warped || !flow_up || !out || H <= 0 || W <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(spynet_pack8_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, (hipStream_t)stream, im1, warped,
+    PM_LAUNCH(spynet_pack8_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, (hipStream_t)stream, im1, warped,
                        flow_up, out, (long)H * W);
     return launch_ok();
 }
@@ -291,14 +292,14 @@ extern "C" int pmctf_spynet_pack8_f32(const float *im1, const float *warped, con
 extern "C" int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2,
                                     float bias, void *stream) {
     if (!x || !y || NC <= 0 || H < 2 || W <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(lift_skip3_kernel, dim3(grid_for((long)NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC,
+    PM_LAUNCH(lift_skip3_kernel, dim3(grid_for((long)NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC,
                        H, W, w0, w1, w2, bias);
     return launch_ok();
 }
 
 extern "C" int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(nearest_up2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream, x,
+    PM_LAUNCH(nearest_up2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream, x,
                        y, N, H, W, C);
     return launch_ok();
 }
@@ -306,21 +307,21 @@ extern "C" int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H
 extern "C" int pmctf_pixel_shuffle2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, int act, float slope,
                                              void *stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream,
+    PM_LAUNCH(pixel_shuffle2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream,
                        x, y, N, H, W, C, act, slope);
     return launch_ok();
 }
 
 extern "C" int pmctf_ffn3_mix_f32(const float *x, float *y, int64_t P, int C, void *stream) {
     if (!x || !y || P <= 0 || C <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(ffn3_mix_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)P, C);
+    PM_LAUNCH(ffn3_mix_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)P, C);
     return launch_ok();
 }
 
 extern "C" int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P,
                                     int C, int Ccell, void *stream) {
     if (!xh || !cell || !cell_out || !hid_out || P <= 0 || C <= 0 || (Ccell != 1 && Ccell != C)) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(lstm_gates_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, xh, cell, cell_out,
+    PM_LAUNCH(lstm_gates_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, xh, cell, cell_out,
                        hid_out, (long)P, C, Ccell);
     return launch_ok();
 }
@@ -329,7 +330,7 @@ extern "C" int pmctf_fourstep_quant_f32(const float *x, const float *params, flo
                                         int N, int H, int W, int k, float log_scale_min, float log_scale_step,
                                         void *stream) {
     if (!x || !params || !so_far || !sym || !idx || N <= 0 || H <= 0 || W <= 0 || k < 0 || k > 3) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(fourstep_quant_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+    PM_LAUNCH(fourstep_quant_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
                        params, so_far, sym, idx, N, H, W, k, log_scale_min, log_scale_step);
     return launch_ok();
 }
@@ -337,7 +338,7 @@ extern "C" int pmctf_fourstep_quant_f32(const float *x, const float *params, flo
 extern "C" int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx,
                                   int64_t total, float log_scale_min, float log_scale_step, void *stream) {
     if (!ll || !params || !ll_hat || !sym || !idx || total <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(ll_quant_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ll, params, ll_hat, sym,
+    PM_LAUNCH(ll_quant_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ll, params, ll_hat, sym,
                        idx, (long)total, log_scale_min, log_scale_step);
     return launch_ok();
 }
@@ -345,7 +346,7 @@ extern "C" int pmctf_ll_quant_f32(const float *ll, const float *params, float *l
 extern "C" int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C,
                                    void *stream) {
     if (!z || !z_hat || !sym || !idx || HW <= 0 || C <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(z_symbols_kernel, dim3(grid_for((long)HW * C)), dim3(256), 0, (hipStream_t)stream, z, z_hat, sym,
+    PM_LAUNCH(z_symbols_kernel, dim3(grid_for((long)HW * C)), dim3(256), 0, (hipStream_t)stream, z, z_hat, sym,
                        idx, HW, C);
     return launch_ok();
 }
@@ -355,14 +356,14 @@ extern "C" int pmctf_mv_fourpart_step_f32(const float *y, const float *common, c
                                           float log_scale_step, void *stream) {
     if (!y || !common || !so_far || !sym || !idx || H <= 0 || W <= 0 || t < 0 || t > 3 || (t > 0 && !sp))
         return PMCTF_EINVAL;
-    hipLaunchKernelGGL(mv_fourpart_kernel, dim3(grid_for((long)H * W * 64)), dim3(256), 0, (hipStream_t)stream, y, common,
+    PM_LAUNCH(mv_fourpart_kernel, dim3(grid_for((long)H * W * 64)), dim3(256), 0, (hipStream_t)stream, y, common,
                        sp, so_far, sym, idx, H, W, t, log_scale_min, log_scale_step);
     return launch_ok();
 }
 
 extern "C" int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat, int64_t HW, void *stream) {
     if (!so_far || !common || !y_hat || HW <= 0) return PMCTF_EINVAL;
-    hipLaunchKernelGGL(mv_dequant_kernel, dim3(grid_for(HW * 64)), dim3(256), 0, (hipStream_t)stream, so_far, common,
+    PM_LAUNCH(mv_dequant_kernel, dim3(grid_for(HW * 64)), dim3(256), 0, (hipStream_t)stream, so_far, common,
                        y_hat, (long)HW);
     return launch_ok();
 }

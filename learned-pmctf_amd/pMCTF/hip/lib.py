@@ -90,6 +90,9 @@ def hip():
         if not os.path.exists(HIP_SO):
             raise NativeLibraryError(
                 f"{HIP_SO} not found: build it with `make -C {PKG_ROOT}` (or __graft_entry__.build())")
+        # torch bundles its own HIP runtime (same SONAME libamdhip64.so.7): it must be the one already loaded
+        # when libpmctf_hip.so is mapped, so that kernels launch on the runtime/streams torch manages.
+        import torch  # noqa: F401
         L = C.CDLL(HIP_SO)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing

@@ -14,6 +14,10 @@ from . import lib as _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
+# Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
+# dominant kernel).  CONV_PROBE = {"match": fn(conv, x) -> bool, "events": [(start, end, flops)]}
+CONV_PROBE = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -80,9 +84,16 @@ class Conv2d:
             assert r is None or tuple(r.shape) == shp
         L = _lib.hip()
         fn = L.pmctf_conv2d_smallcin_f32 if self.small else L.pmctf_conv2d_nhwc_f32
+        probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](self, x)) else None
+        if probe is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(fn(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin, self.Cout,
                       self.KH, self.KW, self.stride, self.pad[0], self.pad[1], int(act), float(slope), _stream()),
                    "conv2d")
+        if probe is not None:
+            e1.record()
+            probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))
         return y
 
 
