@@ -39,7 +39,7 @@ def get_curr_q(q_scale, q_index):
 
 def get_rounded_q(q_scale):
     """stream_helper.py:41-45"""
-    q_scale = np.clip(q_scale, 0.01, 655.)
+    q_scale = float(np.clip(np.asarray(q_scale, dtype=np.float64).reshape(-1)[0], 0.01, 655.))
     q_index = int(np.round(q_scale * 100))
     return q_index / 100, q_index
 

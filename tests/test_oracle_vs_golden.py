@@ -1,0 +1,74 @@
+"""The oracle restatement against fixtures generated from the REAL reference (tools/make_golden.py):
+ATen back-end within fp noise of the fixtures (bit-exact on the generating machine), PM-F32 back-end within the
+stated tolerances and with identical bitstream sizes."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import frames, golden, synth_sd_cpu
+
+W = H = 128
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth_sd_cpu(1)
+
+
+def _close(a, b, tol):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= tol
+
+
+@pytest.mark.parametrize("backend,tol", [("torch", 1e-4), ("cdef", 2e-3)])
+def test_units_and_pwave_stream(sd, backend, tol):
+    import pmctf_synth
+    from pmctf_oracle.model import Oracle, get_curr_q
+    g = golden()
+    o = Oracle(sd, 1, backend)
+    (Y0, C0), (Y1, C1) = frames(W, H, 2)
+    flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, H, W), 3.0))
+    assert np.array_equal(flow.numpy(), g["unit.flow"])
+    with torch.no_grad():
+        assert _close(o.K.flow_warp(Y0, flow), g["unit.warp"], tol)
+        assert _close(o.predict_filter(0, Y0), g["unit.predict_filter"], tol)
+        L, Ht, _, _ = o.forward_MCTF(Y0, Y1, flow)
+        assert _close(L, g["unit.mctf.L"], tol) and _close(Ht, g["unit.mctf.H"], tol)
+        r, c = o.inverse_MCTF(L, Ht, flow)
+        assert _close(r, g["unit.imctf.ref"], tol) and _close(c, g["unit.imctf.cur"], tol)
+        assert _close(o.spynet(Y1.tile((1, 3, 1, 1)) / 255, Y0.tile((1, 3, 1, 1)) / 255), g["unit.spynet"], 1e-5)
+        Hg = torch.from_numpy(g["unit.mctf.H"])
+        sb = o.forward_lift_2d("hp_coder", Hg)
+        for k in ("ll", "lh", "hl", "hh"):
+            assert _close(sb[k].contiguous(), g[f"unit.dwt.{k}"], tol)
+        x_hat, data, trace = o.pwave_compress("hp_coder", Hg, [1, 1, H, W], 3, get_curr_q(o.sd["hp_q_scale.0"], 3))
+        sym = np.concatenate([t[0] for t in trace])
+        idx = np.concatenate([t[1] for t in trace])
+        assert [t[0].size for t in trace] == g["pwave.push_sizes"].tolist()      # 1 LL push + 12 subbands x 4 steps
+        assert np.array_equal(sym, g["pwave.symbols"]) and np.array_equal(idx, g["pwave.indexes"])
+        assert data == g["pwave.file"].tobytes()
+        assert _close(x_hat, g["pwave.x_hat"], tol)
+
+
+def test_gop4_bits_and_psnr_torch_backend(sd):
+    """Full GOP-4 through the harness loop: per-frame bits identical to the reference's file sizes, PSNR within 1e-4 dB."""
+    import pmctf_gop
+    from pmctf_oracle.model import Oracle
+    g = golden()
+    o = Oracle(sd, 1, "torch")
+    fr = frames(W, H, 4)
+    with tempfile.TemporaryDirectory() as td, torch.no_grad():
+        enc = pmctf_gop.encode_gop(o, fr, H, W, 3, td)
+        rec = pmctf_gop.decode_gop(o, enc["frames_coded"])
+        ps = pmctf_gop.gop_psnr(rec, fr, H, W)
+    assert enc["bits"] == g["gop.bits"].tolist()
+    assert enc["bits_mv"] == g["gop.bits_mv"].tolist()
+    assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
+    for i, r in enumerate(enc["results"]):
+        assert _close(r["mv_hat"], g[f"gop.pair{i}.mv_hat"], 1e-5)
+        assert _close(r["H_t"], g[f"gop.pair{i}.H_t"], 1e-3)
+        cur = int(g[f"gop.pair{i}.meta"][2])
+        for name, key in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin")):
+            assert r["files"][name] == g[f"gop.pair{i}.file.{key}"].tobytes()

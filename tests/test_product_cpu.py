@@ -1,0 +1,214 @@
+"""CPU-side checks of the product: parameter tree, C-ABI exports, host range coder vs the oracle, harness
+support code, multi-process scheduling (gloo).  No kernel is launched here."""
+import ctypes
+import glob
+import io
+import json
+import os
+import re
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_state_dict_layout_matches_reference(n):
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", f"state_dict_keys_me{n}.json")))
+    mine = {k: list(v.shape) for k, v in pMCTF(num_me_stages=n).state_dict().items()}
+    assert mine.keys() == ref.keys()
+    assert all(mine[k] == ref[k] for k in ref)
+    sd = pMCTF(num_me_stages=n).state_dict()
+    assert torch.equal(sd["hp_coder.wavelet_transform.lift_h.conv_P1.weight"],
+                       sd["hp_coder.wavelet_transform.lift_v.conv_P1.weight"])          # lift_v aliases lift_h
+    m = sd["hp_coder.context_fusion.3.ll.maskedConv1.mask"][0, 0]
+    assert m.tolist() == [[1, 1, 1], [1, 0, 0], [0, 0, 0]]                               # mask type A
+    m = sd["hp_coder.context_fusion.3.ll.maskedConv2.mask"][0, 0]
+    assert m.tolist() == [[1, 1, 1], [1, 1, 0], [0, 0, 0]]                               # mask type B
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmctf_\w+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from pMCTF.hip import lib
+    hip_syms, rans_syms = _declared("pmctf_hip.h"), _declared("pmctf_rans.h")
+    assert len(hip_syms) >= 22 and len(rans_syms) >= 13
+    H = ctypes.CDLL(lib.HIP_SO)
+    R = ctypes.CDLL(lib.RANS_SO)
+    for s in hip_syms:
+        assert hasattr(H, s), f"libpmctf_hip.so does not export {s}"
+    for s in rans_syms:
+        assert hasattr(R, s), f"libpmctf_rans.so does not export {s}"
+    assert set(lib.exported_symbols()) == set(hip_syms)
+    assert set(lib.rans_exported_symbols()) == set(rans_syms)
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from pMCTF.hip import lib
+    L = lib.hip()
+    assert L.pmctf_conv2d_nhwc_f32(None, None, None, None, None, None, 1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 0, 0.0, None) == -1
+    assert L.pmctf_flow_warp_f32(None, None, None, None, None, 1, 1, 8, 8, 1, 1.0, None) == -1
+    assert L.pmctf_conv2d_packed_size(112, 112, 3, 3) == 7 * 9 * 7 * 256
+    assert L.pmctf_conv2d_packed_bias_size(112) == 112
+
+
+def test_product_path_has_no_cpu_fallback():
+    import pmctf_synth
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = pMCTF(num_me_stages=1)
+    net.update(force=True)
+    fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(128, 128, 2)]
+    with pytest.raises(RuntimeError):
+        net.encode_one_stage(fr[0], fr[1], False, {"mv_feature": None, "ref_mv_y": None}, output_path="/tmp/x.bin",
+                             pic_width=128, pic_height=128, skip_decoding=True)
+    with pytest.raises(NotImplementedError):
+        net.encode_one_stage(fr[0], fr[1], False, {"mv_feature": None, "ref_mv_y": None}, output_path=None)
+
+
+def test_product_tables_match_reference_kat():
+    import hashlib
+    from pMCTF.entropy_models.entropy_models import GaussianEncoder, EntropyCoder, pmf_to_quantized_cdf
+    assert pmf_to_quantized_cdf([.1, .2, .3, .35, .05]).tolist() == [0, 6553, 19659, 39319, 62256, 65536]
+    g = GaussianEncoder()
+    g.update(force=True, entropy_coder=EntropyCoder())
+    cdf, ln, off = g.get_cdf_info()
+    assert hashlib.sha1(np.ascontiguousarray(cdf, np.int32).tobytes()).hexdigest() == "2e0d0570db9b9fd62dfab006b1ac57759e55eb72"
+    assert hashlib.sha1(ln.tobytes()).hexdigest() == "e4fe70191acf4a1d41056176c2599c5d24ac842e"
+    assert hashlib.sha1(off.tobytes()).hexdigest() == "93de49f7943bafffbc0cc66c53a21ff2b31c7b6b"
+    sc = torch.tensor([0, .5, .5, 1, 2, .01, .02, 4, 4, 8, 8, 64, 100, 1e-9, .3, .3])
+    idx = g.build_indexes(sc)
+    sym = torch.tensor([0, 1, -1, 2, -3, 0, 0, 5, -7, 40, -60, 0, 1, 0, 0, -1])
+    ec = g.entropy_coder
+    ec.reset(); g.encode(sym, sc); ec.flush()
+    assert ec.get_encoded_stream().hex() == "01f6e0e56434010000eb9e2b66326159b4"
+    ec.set_stream(ec.get_encoded_stream())
+    assert g.decode_stream(sc, torch.float32, "cpu").int().tolist() == sym.tolist()
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3])
+def test_host_range_coder_matches_oracle_and_round_trips(parts):
+    from pmctf_oracle import clib, entropy
+    from pMCTF.entropy_models.entropy_models import EntropyCoder
+    tab = entropy.GaussianTables()
+    cdf, ln, off = tab.cdf_info()
+    rng = np.random.default_rng(parts)
+    n = 200003
+    idx = rng.integers(0, 256, n).astype(np.int16)
+    idx[rng.random(n) < 0.5] = 0
+    sym = np.round(rng.laplace(0, 1, n) * tab.scale_table.numpy()[idx] * 1.5).astype(np.int64)
+    sym[rng.random(n) < 0.001] = 30000          # long bypass runs
+    sym[rng.random(n) < 0.001] = -30000
+    sym = np.clip(sym, -30000, 30000).astype(np.int16)
+    ec = EntropyCoder(False, parts)
+    ec.reset()
+    for a, b in ((0, n // 3), (n // 3, n)):      # two pushes
+        ec.encode_with_indexes(sym[a:b], idx[a:b], cdf, ln, off)
+    ec.flush()
+    s = ec.get_encoded_stream()
+    assert s[0] == ((parts - 1) << 4) + (1 if parts == 1 or True else 0) or parts > 1
+    if parts == 1:
+        o = clib.RansEncoder(); o.reset()
+        for a, b in ((0, n // 3), (n // 3, n)):
+            o.encode_with_indexes(sym[a:b], idx[a:b], cdf, ln, off)
+        o.flush()
+        assert o.get_encoded_stream().tobytes() == s
+        ec.set_stream(s)
+        out = ec.decode_stream(torch.from_numpy(idx), cdf, ln, off).numpy().astype(np.int16)
+        assert np.array_equal(out, sym)
+    with tempfile.TemporaryDirectory() as td:
+        from pMCTF.hip import lib
+        path = os.path.join(td, "s.bin")
+        hdr = b"HEAD"
+        size = lib.rans().pmctf_rans_encoder_write_file(ec.encoder, hdr, len(hdr), path.encode())
+        assert size == len(hdr) + len(s) == os.path.getsize(path)
+        assert open(path, "rb").read() == hdr + s
+
+
+def test_stream_framing_and_helpers():
+    from pMCTF.utils import stream_helper as sh
+    assert sh.get_padding_size(1080, 1920, 128) == (0, 0, 0, 72)
+    assert sh.get_downsampled_shape(1152, 1920, 64) == (18, 30)
+    assert sh.get_rounded_q(np.array([[[[1.2345]]]])) == (1.23, 123)
+    assert sh.get_rounded_q(0.001) == (0.01, 1)
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "a.bin")
+        sh.encode_p(b"abc", 0, p)
+        assert open(p, "rb").read() == struct.pack(">H", 0) + struct.pack(">I", 3) + b"abc"
+        assert sh.decode_p(p) == (0, b"abc")
+        sh.encode_image(1080, 1920, 1, b"xyz!", p)
+        assert open(p, "rb").read() == struct.pack(">III", 1080, 1920, 1) + struct.pack(">I", 4) + b"xyz!"
+        assert sh.decode_image(p) == (1080, 1920, 1, b"xyz!")
+    assert sh.image_header(540, 960, 2, 7) == struct.pack(">IIII", 540, 960, 2, 7)
+
+
+def test_yuv_reader_and_eval_utils():
+    import pmctf_synth
+    from pMCTF.utils.yuv_reader import YUVReader
+    from pMCTF.utils.util import ycbcr2rgb, yuv_420_to_444
+    from pMCTF.utils.video_eval_utils import dump_json, generate_log_json, str2bool
+    fr = pmctf_synth.synth_yuv420(64, 48, 3)
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "v.yuv")
+        with open(p, "wb") as f:
+            for y, u, v in fr:
+                f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+        r = YUVReader(p, 64, 48)
+        for y, u, v in fr:
+            Y, Cb, Cr = r.read_one_frame()
+            assert np.array_equal(Y, y) and np.array_equal(Cb, u) and np.array_equal(Cr, v)
+    t = yuv_420_to_444((torch.rand(1, 1, 8, 8), torch.rand(1, 1, 4, 4), torch.rand(1, 1, 4, 4)))
+    assert t.shape == (1, 3, 8, 8)
+    rgb = ycbcr2rgb(torch.tensor([[[[100.]], [[128.]], [[128.]]]]))
+    assert torch.allclose(rgb, torch.full((1, 3, 1, 1), 100.))
+    assert str2bool("1") and not str2bool("no")
+    log = generate_log_json(4, [0, 1, 1, 1], [800., 400., 400., 400.], [0, .01, .01, .01], [30., 31., 32., 33.],
+                            [29.] * 4, [0.9] * 4, 100, 1.5)
+    assert log["i_frame_num"] == 1 and log["p_frame_num"] == 3
+    assert abs(log["ave_all_frame_bpp"] - 2000. / 400) < 1e-12 and abs(log["ave_all_frame_psnr"] - 31.5) < 1e-12
+    f = io.StringIO(); dump_json(log, f, float_digits=6, indent=2)
+    assert json.loads(f.getvalue())["ave_i_frame_bpp"] == 8.0
+
+
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import pmctf_dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n_gops, gop = 5, 4
+    mine = pmctf_dist.shard_gops(n_gops, rank, world)
+    local = {g: ([1000.0 * g + i for i in range(gop)], [30.0 + g + 0.1 * i for i in range(gop)]) for g in mine}
+    bits, psnr = pmctf_dist.gather_gop_metrics(local, n_gops, gop, dist)
+    q.put((rank, mine, bits.tolist(), psnr.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gop_sharding_world_size_2_gloo():
+    """N>1 path: every GOP coded by exactly one rank, metrics reassembled in GOP order on all ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shards = sorted(sum((r[1] for r in res), []))
+    assert shards == [0, 1, 2, 3, 4]
+    expect_bits = [[1000.0 * g + i for i in range(4)] for g in range(5)]
+    for _, _, bits, psnr in res:
+        assert bits == expect_bits
+        assert abs(psnr[3][2] - 33.2) < 1e-12
