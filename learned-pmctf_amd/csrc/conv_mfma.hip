@@ -13,6 +13,7 @@
 // (every workgroup reads the same <=0.5 MB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "pm_device_math.h"
 #include "launch.h"
@@ -151,6 +152,175 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Pipelined variant (same arithmetic, same sum order): the input patch of chunk cb+1 is fetched into
+// registers while chunk cb is being multiplied and written to the second LDS buffer afterwards (one
+// barrier per chunk); the weight fragments of the next tap are loaded one tap ahead; <= 256 VGPRs so
+// that two workgroups share a CU (2 waves/SIMD) and fill each other's stalls.
+template <int MT, int NT, int TW16, int MAXP>
+__global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TW = TW16 * 16;
+    constexpr int TH = NT * WAVES / TW16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mb = blockIdx.z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
+    const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
+    const int taps = a.KH * a.KW;
+    const int bufsz = LH * LW * CP;
+
+    f32x4 acc[MT][NT];
+    {
+        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+        }
+    }
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int seg = wave * NT + nt;
+        const int r = seg / TW16, c16 = seg - r * TW16;
+        boff[nt] = ((r * a.S) * LW + (c16 * 16 + (lane & 15)) * a.S) * CP + (lane >> 4);
+    }
+    const int E = LH * LW * 4;
+    // staging: thread `tid` owns float4 slots e = tid + 256*j of the patch (pixel e>>2, channel quad e&3)
+    f32x4 pre[MAXP];
+    auto fetch = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = tid + 256 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < E) {
+                const int pix = e >> 2, part = e & 3;
+                const int ly = pix / LW, lx = pix - ly * LW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + cb * CB + part * 4);
+            }
+            pre[j] = v;
+        }
+    };
+    auto stash = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = tid + 256 * j;
+            if (e < E) {
+                float2 *dst = (float2 *)(buf + (e >> 2) * CP + (e & 3) * 4);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    const float *wq = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;   // walks [cb][tap] contiguously
+    const long wsteps = (long)a.ncb * taps;
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *(const f32x4 *)(wq + mt * 256);
+    fetch(0);
+    stash(lds);
+    __syncthreads();
+    long wstep = 0;
+    // B operands: two register sets; set (ks&1) feeds k-step ks while the other set receives the next k-step
+    // (or the next tap's first k-step), so every LDS read is issued one full k-step (MT*NT MFMAs) ahead of its use.
+    float b0[NT], b1[NT];
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        const float *cur = lds + (cb & 1) * bufsz;
+        const bool more = cb + 1 < a.ncb;
+        if (more) fetch(cb + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[boff[nt]];
+        int ky = 0, kx = 0;
+        for (int tap = 0; tap < taps; ++tap) {
+            ++wstep;
+            {   // next tap's weight fragments, always loaded (the last step re-reads its own block: no branch)
+                const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * (MT * 256) + mt * 256);
+            }
+            const float *bbase = cur + (ky * LW + kx) * CP;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+            // first k-step of the next tap (the last tap of a chunk harmlessly re-reads its own first k-step)
+            const float *bnext = tap + 1 < taps ? cur + (ky * LW + kx) * CP : bbase;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = bbase[boff[nt] + 4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][0], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = bbase[boff[nt] + 8];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][1], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = bbase[boff[nt] + 12];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][2], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = bnext[boff[nt]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][3], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+        }
+        if (more) stash(lds + ((cb + 1) & 1) * bufsz);
+        __syncthreads();
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int seg = wave * NT + nt;
+        const int r = seg / TW16, c16 = seg - r * TW16;
+        const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            if (co >= a.Cout) continue;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (co + i < a.Cout) {
+                        float s = v[i];
+                        if (a.res1) s = s + a.res1[pbase + co + i];
+                        if (a.res2) s = s + a.res2[pbase + co + i];
+                        a.y[pbase + co + i] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
 void choose_mt(int Cout, int &MT, int &MB) {
     const int tiles = (Cout + 15) / 16;
@@ -175,6 +345,20 @@ int launch(const ConvArgs &a, int MB, hipStream_t st) {
     const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
     const size_t smem = (size_t)LH * LW * CP * sizeof(float);
     if (smem > 160 * 1024) return PMCTF_EINVAL;
+    {   // pipelined variant: double-buffered patch (2*smem <= 80 KB so two workgroups fit a CU), <= 9 slots/thread
+        static const bool v1_only = getenv("PMCTF_CONV_V1") != nullptr;
+        const int slots = (LH * LW * 4 + 255) / 256;
+        dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
+        static const bool v2_only = getenv("PMCTF_CONV_V2") != nullptr;
+        // measured (tools/bench_conv.py): the pipelined variant wins for the wide-cout tiles (MT>=7) and for 1x1
+        // filters; the single-buffer variant keeps 3 waves/SIMD for MT<=4 and wins on 3x3/7x7 there.
+        const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1);
+        if (!v1_only && prefer_v2 && (a.Cin % CB) == 0 && 2 * smem <= 80 * 1024 && slots <= 9) {
+            if (slots <= 6) PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 6>), grid, dim3(256), 2 * smem, st, b);
+            else PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 9>), grid, dim3(256), 2 * smem, st, b);
+            return pm_launch_status();
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)conv_mfma_kernel<MT, NT, TW16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -190,7 +374,17 @@ int dispatch_tile(const ConvArgs &a, int MB, hipStream_t st) {
     // big tile 8x32 (NT=4) when the image is large and stride 1; 8x16 (NT=2) for stride 2 / mid sizes;
     // 4x16 (NT=1) for small planes so that more than a handful of workgroups exist.
     const long px = (long)a.Ho * a.Wo * a.N;
-    if (MT < 8 && a.S == 1 && px >= 256L * 256 * 2 && a.KH <= 7) return launch<MT, 4, 2>(a, MB, st);
+    static const char *force_nt = getenv("PMCTF_CONV_NT");
+    if (force_nt) {
+        const int f = atoi(force_nt);
+        if (f == 4 && MT < 8 && a.S == 1) return launch<MT, 4, 2>(a, MB, st);
+        if (f == 2) return launch<MT, 2, 1>(a, MB, st);
+        if (f == 1) return launch<MT, 1, 1>(a, MB, st);
+    }
+    // measured on MI355X (tools/bench_conv.py): 8x32 tiles only pay when there are >> 256 of them; the wide-cout
+    // kernels (MT>=7) prefer 4x16 tiles on everything smaller (more workgroups -> less tail quantisation).
+    if (MT < 8 && a.S == 1 && px >= 400000L && a.KH <= 7) return launch<MT, 4, 2>(a, MB, st);
+    if (MT >= 7) return launch<MT, 1, 1>(a, MB, st);
     if (px >= 64L * 64 * 4) return launch<MT, 2, 1>(a, MB, st);
     return launch<MT, 1, 1>(a, MB, st);
 }

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on the shapes of the 1080p encode path (HIP events, TFLOP/s)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
+import torch  # noqa: E402
+from pMCTF.hip import ops  # noqa: E402
+
+SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
+    ("ctx112 L0 luma 576x960", 1, 576, 960, 112, 112, 3, 1, 1),
+    ("ctx112 L0 chroma 2x288x480", 2, 288, 480, 112, 112, 3, 1, 1),
+    ("ctx112 L1 luma 288x480", 1, 288, 480, 112, 112, 3, 1, 1),
+    ("ctx112 L2 luma 144x240", 1, 144, 240, 112, 112, 3, 1, 1),
+    ("ctx112 L3 luma 72x120", 1, 72, 120, 112, 112, 3, 1, 1),
+    ("post64 luma 1152x1920", 1, 1152, 1920, 64, 64, 3, 1, 1),
+    ("spynet 32->64 7x7 1152x1920", 1, 1152, 1920, 32, 64, 7, 1, 3),
+    ("spynet 8->32 7x7 1152x1920", 1, 1152, 1920, 8, 32, 7, 1, 3),
+    ("pu 16->16 3x3 1152x1920", 1, 1152, 1920, 16, 16, 3, 1, 1),
+    ("pu 16->1 3x3 1152x1920", 1, 1152, 1920, 16, 1, 3, 1, 1),
+    ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
+    ("lstm 32->32 576x960", 1, 576, 960, 32, 32, 3, 1, 1),
+]
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    only = sys.argv[2] if len(sys.argv) > 2 else None
+    torch.manual_seed(0)
+    for name, N, H, W, Cin, Cout, K, S, P in SHAPES:
+        if only and only not in name:
+            continue
+        w = torch.randn(Cout, Cin, K, K) * 0.05
+        b = torch.randn(Cout)
+        conv = ops.Conv2d(w, b, S, (P, P))
+        x = torch.randn(N, H, W, Cin, device="cuda")
+        y = conv(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            conv(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * N * y.shape[1] * y.shape[2] * Cout * Cin * K * K
+        print(f"{name:34s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  ({fl / ms / 1e9 / 157.3 * 100:5.1f} % of f32 MFMA peak)")
+
+
+if __name__ == "__main__":
+    main()
