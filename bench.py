@@ -141,9 +141,15 @@ def main():
     avg = sum(durs) / len(durs) if durs else float("nan")
     achieved = flops / avg / 1e12 if durs else float("nan")
     peak = 157.3
+    traffic = None      # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_dominant_kernel.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<7,4,2> (3x3 112->112, f32 MFMA 16x16x4)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "launches": len(durs), "avg_launch_ms": avg * 1e3, "flops_per_launch": flops, "traffic": None}
+                "launches": len(durs), "avg_launch_ms": avg * 1e3, "flops_per_launch": flops, "traffic": traffic}
 
     if rank == 0:
         enc = last["enc"]
@@ -161,6 +167,7 @@ def main():
             "roofline": roofline,
             "bpp": sum(enc["bits"]) / (args.gop * W * H),
             "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
+            "host": dict(net.engine().stats),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.gop)

@@ -321,6 +321,171 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Barrier-free variant for large planes: every WAVE owns a 4x16-pixel output tile (NT = 4 rows of 16 px), stages
+// its own input patch ((3*S+KH) x (15*S+KW) pixels x 16 channels) into a wave-private, double-buffered LDS region
+// and never synchronises with the other waves of the workgroup (the LDS operations of one wave are ordered), so the
+// two waves sharing a SIMD drift apart and keep the matrix pipe busy across chunk boundaries.  Same arithmetic and
+// sum order as the other variants.  The workgroup (4 waves = 8x32 pixels) only groups waves for dispatch.
+template <int MT, int MAXP>
+__global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
+    constexpr int NT = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mb = blockIdx.z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
+    const int LH = 3 * a.S + a.KH, LW = 15 * a.S + a.KW;
+    const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
+    const int taps = a.KH * a.KW;
+    const int bufsz = LH * LW * CP;
+    float *wlds = lds + wave * 2 * bufsz;
+
+    f32x4 acc[MT][NT];
+    {
+        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+        }
+    }
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        boff[nt] = ((nt * a.S) * LW + (lane & 15) * a.S) * CP + (lane >> 4);
+    }
+    const int E = LH * LW * 4;
+    // staging: lane owns float4 slots e = lane + 64*j of this wave's patch (pixel e>>2, channel quad e&3)
+    f32x4 pre[MAXP];
+    auto fetch = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = lane + 64 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < E) {
+                const int pix = e >> 2, part = e & 3;
+                const int ly = pix / LW, lx = pix - ly * LW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + cb * CB + part * 4);
+            }
+            pre[j] = v;
+        }
+    };
+    auto stash = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = lane + 64 * j;
+            if (e < E) {
+                float2 *dst = (float2 *)(buf + (e >> 2) * CP + (e & 3) * 4);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    const float *wq = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;   // walks [cb][tap] contiguously
+    const long wsteps = (long)a.ncb * taps;
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *(const f32x4 *)(wq + mt * 256);
+    fetch(0);
+    stash(wlds);
+    long wstep = 0;
+    // B operands: two register sets; set (ks&1) feeds k-step ks while the other set receives the next k-step
+    // (or the next tap's first k-step), so every LDS read is issued one full k-step (MT*NT MFMAs) ahead of its use.
+    float b0[NT], b1[NT];
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        const float *cur = wlds + (cb & 1) * bufsz;
+        const bool more = cb + 1 < a.ncb;
+        if (more) fetch(cb + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[boff[nt]];
+        int ky = 0, kx = 0;
+        for (int tap = 0; tap < taps; ++tap) {
+            ++wstep;
+            {   // next tap's weight fragments, always loaded (the last step re-reads its own block: no branch)
+                const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * (MT * 256) + mt * 256);
+            }
+            const float *bbase = cur + (ky * LW + kx) * CP;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+            // first k-step of the next tap (the last tap of a chunk harmlessly re-reads its own first k-step)
+            const float *bnext = tap + 1 < taps ? cur + (ky * LW + kx) * CP : bbase;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = bbase[boff[nt] + 4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][0], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = bbase[boff[nt] + 8];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][1], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = bbase[boff[nt] + 12];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][2], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = bnext[boff[nt]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][3], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+        }
+        // the other buffer was last read in chunk cb-1 by this same wave: in-order LDS makes the overwrite safe
+        if (more) stash(wlds + ((cb + 1) & 1) * bufsz);
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + nt, ox = ox0 + (lane & 15);
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            if (co >= a.Cout) continue;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (co + i < a.Cout) {
+                        float s = v[i];
+                        if (a.res1) s = s + a.res1[pbase + co + i];
+                        if (a.res2) s = s + a.res2[pbase + co + i];
+                        a.y[pbase + co + i] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 // choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
 void choose_mt(int Cout, int &MT, int &MB) {
     const int tiles = (Cout + 15) / 16;
@@ -345,6 +510,18 @@ int launch(const ConvArgs &a, int MB, hipStream_t st) {
     const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
     const size_t smem = (size_t)LH * LW * CP * sizeof(float);
     if (smem > 160 * 1024) return PMCTF_EINVAL;
+    if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
+        static const char *wv = getenv("PMCTF_CONV_WAVE");
+        const bool use_wave = wv ? atoi(wv) != 0 : true;
+        const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
+        const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+        const int wslots = (PH * PW * 4 + 63) / 64;
+        if (use_wave && MT >= 4 && (a.Cin % CB) == 0 && wsmem <= 80 * 1024 && wslots <= 7) {
+            dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
+            PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
+            return pm_launch_status();
+        }
+    }
     {   // pipelined variant: double-buffered patch (2*smem <= 80 KB so two workgroups fit a CU), <= 9 slots/thread
         static const bool v1_only = getenv("PMCTF_CONV_V1") != nullptr;
         const int slots = (LH * LW * 4 + 255) / 256;

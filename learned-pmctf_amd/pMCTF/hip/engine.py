@@ -152,6 +152,11 @@ class HipEngine:
         self.lstep = gaussian_tables["log_scale_step"]
         self.coder = RangeCoderPool(coder_threads)
         self.keep_streams = False       # tests: keep bytes + symbol traces of each stream
+        # luma and chroma of a pair are independent once mv_hat exists: they are coded on two side streams so that
+        # the small-plane kernels of one fill the tails of the other (per-stream LSTM state keeps them apart)
+        self.side_streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+        self.multi_stream = False       # measured: no gain (the big kernels already fill every SIMD's register file)
+        self.stats = {"enqueue_s": 0.0, "pair_s": 0.0, "pairs": 0}
 
     # ------------------------------------------------------------------ packed layers
     def conv(self, p, stride=1, padding=0):
@@ -159,6 +164,7 @@ class HipEngine:
         c = self._convs.get(key)
         if c is None:
             c = ops.Conv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride, (padding, padding), self.dev)
+            torch.cuda.synchronize(self.dev)      # packed weights are used from several streams later
             self._convs[key] = c
         return c
 
@@ -166,6 +172,7 @@ class HipEngine:
         c = self._dw.get(p)
         if c is None:
             c = ops.DepthwiseConv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), self.dev)
+            torch.cuda.synchronize(self.dev)
             self._dw[p] = c
         return c
 
@@ -174,6 +181,7 @@ class HipEngine:
         t = self._lin.get((H, W))
         if t is None:
             t = (torch.linspace(-1.0, 1.0, W).to(self.dev), torch.linspace(-1.0, 1.0, H).to(self.dev))
+            torch.cuda.synchronize(self.dev)
             self._lin[(H, W)] = t
         return t
 
@@ -483,24 +491,23 @@ class HipEngine:
 
     def ctx_init(self, N, H, W):
         z = lambda c: torch.zeros((N, H, W, c), dtype=torch.float32, device=self.dev)
-        self.l3 = [z(3), z(1)]          # init_sequential quirk: 1-channel cell state (long_context.py:163-164)
-        self.l1 = [z(32), z(32)]
-        self.l2 = [z(32), z(32)]
+        # init_sequential quirk: LSTM3's cell state starts with 1 channel (long_context.py:163-164)
+        return {"l1": [z(32), z(32)], "l2": [z(32), z(32)], "l3": [z(3), z(1)]}
 
     def ctx_upsample(self, p, x):
         return self.conv(p + ".conv", 1, 1)(ops.nearest_up2(x))
 
-    def ctx_forward_one_subband(self, coder, subband, name, lvl):
+    def ctx_forward_one_subband(self, coder, st, subband, name, lvl):
         p = f"{coder}.context_prediction"
         N, _, H, W = subband.shape
-        self.l1 = self.lstm(p + ".LSTM1", subband.view(N, H, W, 1), self.l1)
-        self.l2 = self.lstm(p + ".LSTM2", self.l1[0], self.l2)
-        self.l3 = self.lstm(p + ".LSTM3", self.l2[0], self.l3)
+        st["l1"] = self.lstm(p + ".LSTM1", subband.view(N, H, W, 1), st["l1"])
+        st["l2"] = self.lstm(p + ".LSTM2", st["l1"][0], st["l2"])
+        st["l3"] = self.lstm(p + ".LSTM3", st["l2"][0], st["l3"])
         if name == "hh" and lvl > 0:
-            for st, nm in ((self.l1, "1"), (self.l2, "2"), (self.l3, "3")):
-                st[0] = self.ctx_upsample(f"{p}.deconv_h{nm}.{lvl - 1}", st[0])
-                st[1] = self.ctx_upsample(f"{p}.deconv_c{nm}.{lvl - 1}", st[1])
-        return self.l3[0]
+            for key, nm in (("l1", "1"), ("l2", "2"), ("l3", "3")):
+                st[key][0] = self.ctx_upsample(f"{p}.deconv_h{nm}.{lvl - 1}", st[key][0])
+                st[key][1] = self.ctx_upsample(f"{p}.deconv_c{nm}.{lvl - 1}", st[key][1])
+        return st["l3"][0]
 
     # ------------------------------------------------------------------ a14 PostProcess (postprocessing.py:35-44)
     def post_process(self, coder, x, in_div=1.0, out_mul=1.0):
@@ -547,8 +554,8 @@ class HipEngine:
         ll_hat = ops.ll_quant(llq, params, stream.sym, stream.idx, stream.take(llq.numel(), "gauss"), self.lmin,
                               self.lstep)
         hat[self.L - 1]["ll"] = ll_hat
-        self.ctx_init(N, ll.shape[2], ll.shape[3])
-        context = self.ctx_forward_one_subband(coder, ll_hat, "ll", self.L - 1)
+        lstm_state = self.ctx_init(N, ll.shape[2], ll.shape[3])
+        context = self.ctx_forward_one_subband(coder, lstm_state, ll_hat, "ll", self.L - 1)
         for lvl in range(self.L - 1, -1, -1):
             for sidx, sb in enumerate(("lh", "hl", "hh")):
                 h, w = context.shape[1], context.shape[2]
@@ -558,7 +565,7 @@ class HipEngine:
                 s_curr = ew(EW_CLAMP_MULS, y[lvl][sb], alpha=q_scale, beta=clip)
                 s_hat = self.fusion_compress(f"{coder}.context_fusion.{lvl}.{sb}", s_curr, ctx, prev, stream)
                 hat[lvl][sb] = s_hat
-                context = self.ctx_forward_one_subband(coder, s_hat, sb, lvl)
+                context = self.ctx_forward_one_subband(coder, lstm_state, s_hat, sb, lvl)
         out = None
         rec_ll = ew(EW_DIVS, hat[self.L - 1]["ll"], alpha=q_scale_ll)
         for lvl in range(self.L - 1, -1, -1):

@@ -155,22 +155,54 @@ class pMCTF(nn.Module):
         jobs = {"mv": eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0), mv_out, keep)}
         mv_hat = mv["mv_hat"]
         base = osp.basename(output_path)
-        luma = eng.compress_one_stage(c(ref_y), c(cur_y), code_lt, mv_hat, False, stage_idx, q_index)
-        jobs["H"] = eng.coder.submit(luma["H_stream"], eng.tables,
-                                     lambda n: image_header(pic_height, pic_width, 1, n), output_path, keep)
-        if code_lt:
-            jobs["L"] = eng.coder.submit(luma["L_stream"], eng.tables,
-                                         lambda n: image_header(pic_height, pic_width, 1, n),
-                                         output_path.replace(base, "0_main.bin"), keep)
         file_name_c = output_path.replace(".bin", "_C_main.bin")
-        chroma = eng.compress_one_stage(c(ref_chroma), c(cur_chroma), code_lt, mv_hat, True, stage_idx, q_index)
-        jobs["Hc"] = eng.coder.submit(chroma["H_stream"], eng.tables,
-                                      lambda n: image_header(pic_height // 2, pic_width // 2, 2, n), file_name_c, keep)
-        if code_lt:
-            jobs["Lc"] = eng.coder.submit(chroma["L_stream"], eng.tables,
-                                          lambda n: image_header(pic_height // 2, pic_width // 2, 2, n),
-                                          output_path.replace(base, "0_C_main.bin"), keep)
+        ry, cy, rc, cc = c(ref_y), c(cur_y), c(ref_chroma), c(cur_chroma)
+
+        def code_luma():
+            r = eng.compress_one_stage(ry, cy, code_lt, mv_hat, False, stage_idx, q_index)
+            jobs["H"] = eng.coder.submit(r["H_stream"], eng.tables,
+                                         lambda n: image_header(pic_height, pic_width, 1, n), output_path, keep)
+            if code_lt:
+                jobs["L"] = eng.coder.submit(r["L_stream"], eng.tables,
+                                             lambda n: image_header(pic_height, pic_width, 1, n),
+                                             output_path.replace(base, "0_main.bin"), keep)
+            return r
+
+        def code_chroma():
+            r = eng.compress_one_stage(rc, cc, code_lt, mv_hat, True, stage_idx, q_index)
+            jobs["Hc"] = eng.coder.submit(r["H_stream"], eng.tables,
+                                          lambda n: image_header(pic_height // 2, pic_width // 2, 2, n), file_name_c,
+                                          keep)
+            if code_lt:
+                jobs["Lc"] = eng.coder.submit(r["L_stream"], eng.tables,
+                                              lambda n: image_header(pic_height // 2, pic_width // 2, 2, n),
+                                              output_path.replace(base, "0_C_main.bin"), keep)
+            return r
+
+        if eng.multi_stream:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            outs = []
+            for side, fn in zip(eng.side_streams, (code_luma, code_chroma)):
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    outs.append(fn())
+            for side in eng.side_streams:
+                main.wait_stream(side)
+            luma, chroma = outs
+            for r in outs:                 # results are consumed on the caller's stream from now on
+                for k in ("L_t", "H_t", "H_t_hat", "L_t_hat"):
+                    if r[k] is not None:
+                        r[k].record_stream(main)
+        else:
+            luma = code_luma()
+            chroma = code_chroma()
+        t_enq = time.time() - start
         done = {k: j.result() for k, j in jobs.items()}
+        eng.stats["enqueue_s"] += t_enq
+        eng.stats["pair_s"] += time.time() - start
+        eng.stats["pairs"] += 1
         encoding_time = time.time() - start
         bits = {k: v[0] * 8.0 for k, v in done.items()}
         result = {
