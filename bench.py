@@ -31,6 +31,12 @@ def cpu_baseline(width, height, gop):
     from pmctf_oracle.model import Oracle
     from pMCTF.models.video.pMCTF_L import pMCTF
     w, h = 448, 256
+    # a 1-GPU box owns a 16-CPU share of the host: use that many threads (and report them as `cores`)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
     net = pMCTF(num_me_stages=1)
     sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
     orc = Oracle(sd, 1, "torch")
@@ -71,8 +77,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PMCTF_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI on the 8-GPU node
+        if os.environ.get("PMCTF_BENCH_SINGLE_DEVICE"):               # rehearsal of the N>1 path on a 1-GPU box
+            local_rank = 0
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -129,7 +138,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ops.CONV_PROBE = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -147,7 +156,7 @@ def main():
             traffic = json.load(f)["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<7,4,2> (3x3 112->112, f32 MFMA 16x16x4)",
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_wave_kernel<7,7> (3x3 112->112 on a 576x960 subband, f32 MFMA 16x16x4)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "launches": len(durs), "avg_launch_ms": avg * 1e3, "flops_per_launch": flops, "traffic": traffic}
 
