@@ -27,12 +27,44 @@ constexpr uint32_t kBypassPrecision = 4;
 constexpr uint32_t kMaxBypassVal = (1u << kBypassPrecision) - 1;
 constexpr uint64_t kRansL = 1ull << 31;
 
+// One CDF interval, with the constants that turn x / range into a multiply (Granlund-Montgomery, exact for every
+// 64-bit x): q = (t + ((x - t) >> 1)) >> sh1 with t = mulhi(x, magic); range == 1 and powers of two included.
+struct Entry {
+    uint64_t magic;
+    uint32_t start, range;
+    uint32_t sh1;      // l - 1 (l = ceil(log2 range)); unused when range == 1
+    uint32_t pad;
+};
+
+struct Table {          // a registered (cdfs, sizes) pair; entries[row * cols + value]
+    const int32_t *key_ptr;
+    int rows, cols;
+    uint64_t checksum;
+    uint32_t base;      // first index of this table in the encoder's flat entry array
+};
+
+constexpr uint32_t kBypassFlag = 0x80000000u;
+
 struct Part {
-    std::vector<uint32_t> steps;  // (range << 16) | start ; range == 0 -> bypass digit in `start`
+    std::vector<uint32_t> steps;  // entry index, or kBypassFlag | 4-bit digit
     std::vector<uint8_t> stream;
 };
 
-inline void push_value(std::vector<uint32_t> &steps, const int32_t *cdf, int32_t max_value, int32_t value) {
+inline Entry make_entry(uint32_t start, uint32_t range) {
+    Entry e;
+    e.start = start; e.range = range; e.pad = 0; e.magic = 0; e.sh1 = 0;
+    if (range > 1) {
+        uint32_t l = 0;
+        while ((1ull << l) < range) ++l;
+        const unsigned __int128 num = ((unsigned __int128)1 << 64) * (((uint64_t)1 << l) - range);
+        e.magic = (uint64_t)(num / range) + 1;
+        e.sh1 = l - 1;
+    }
+    return e;
+}
+
+// row_base: index of this row's first entry in the flat entry array
+inline void push_value(std::vector<uint32_t> &steps, uint32_t row_base, int32_t max_value, int32_t value) {
     uint32_t raw_val = 0;
     if (value < 0) {
         raw_val = (uint32_t)(-2 * value - 1);
@@ -41,23 +73,22 @@ inline void push_value(std::vector<uint32_t> &steps, const int32_t *cdf, int32_t
         raw_val = (uint32_t)(2 * (value - max_value));
         value = max_value;
     }
-    const uint32_t start = (uint32_t)cdf[value];
-    const uint32_t range = (uint32_t)(cdf[value + 1] - cdf[value]);
-    steps.push_back(((range & 0xFFFFu) << 16) | (start & 0xFFFFu));
+    steps.push_back(row_base + (uint32_t)value);
     if (value == max_value) {
         int32_t n_bypass = 0;
         while ((raw_val >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
         int32_t val = n_bypass;
         while (val >= (int32_t)kMaxBypassVal) {
-            steps.push_back(kMaxBypassVal);
+            steps.push_back(kBypassFlag | kMaxBypassVal);
             val -= kMaxBypassVal;
         }
-        steps.push_back((uint32_t)val);
-        for (int32_t j = 0; j < n_bypass; ++j) steps.push_back((raw_val >> (j * kBypassPrecision)) & kMaxBypassVal);
+        steps.push_back(kBypassFlag | (uint32_t)val);
+        for (int32_t j = 0; j < n_bypass; ++j)
+            steps.push_back(kBypassFlag | ((raw_val >> (j * kBypassPrecision)) & kMaxBypassVal));
     }
 }
 
-void flush_part(Part &p) {
+void flush_part(Part &p, const Entry *entries) {
     const size_t n = p.steps.size();
     std::vector<uint32_t> out(n + 2);
     uint32_t *ptr = out.data() + out.size();
@@ -65,12 +96,19 @@ void flush_part(Part &p) {
     const uint32_t *s = p.steps.data();
     for (size_t i = n; i-- > 0;) {
         const uint32_t w = s[i];
-        const uint32_t range = w >> 16;
-        if (range != 0) {
-            const uint32_t start = w & 0xFFFFu;
-            const uint64_t x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)range;
+        if (!(w & kBypassFlag)) {
+            const Entry &e = entries[w];
+            const uint64_t range = e.range;
+            const uint64_t x_max = ((kRansL >> kPrecision) << 32) * range;
             if (x >= x_max) { *--ptr = (uint32_t)x; x >>= 32; }
-            x = ((x / range) << kPrecision) + (x % range) + start;
+            uint64_t q;
+            if (range == 1) {
+                q = x;
+            } else {
+                const uint64_t t = (uint64_t)(((unsigned __int128)x * e.magic) >> 64);
+                q = (t + ((x - t) >> 1)) >> e.sh1;
+            }
+            x = (q << kPrecision) + (x - q * range) + e.start;      // ((x / f) << 16) + (x % f) + start
         } else {
             const uint32_t val = w & 0xFFFFu;
             const uint64_t x_max = ((kRansL >> 16) << 32) * (uint64_t)(1u << (16 - kBypassPrecision));
@@ -92,6 +130,30 @@ void flush_part(Part &p) {
 struct pmctf_rans_encoder {
     std::vector<Part> parts;
     std::vector<uint8_t> stream;  // assembled by flush()
+    std::vector<Entry> entries;   // flat interval table of every registered CDF table
+    std::vector<Table> tables;
+
+    // find or register (cdfs, sizes); tables are tiny (<= 26 k ints) so the checksum is recomputed per call
+    uint32_t table_base(const int32_t *cdfs, int rows, int cols, const int32_t *sizes) {
+        uint64_t h = 1469598103934665603ull;
+        for (long i = 0; i < (long)rows * cols; ++i) h = (h ^ (uint32_t)cdfs[i]) * 1099511628211ull;
+        for (int i = 0; i < rows; ++i) h = (h ^ (uint32_t)sizes[i]) * 1099511628211ull;
+        for (const Table &t : tables)
+            if (t.rows == rows && t.cols == cols && t.checksum == h) return t.base;
+        Table t{cdfs, rows, cols, h, (uint32_t)entries.size()};
+        entries.resize(entries.size() + (size_t)rows * cols);
+        for (int r = 0; r < rows; ++r) {
+            const int n = sizes[r] - 1;          // number of symbols in this row (incl. the escape symbol)
+            for (int v = 0; v < cols; ++v) {
+                Entry e = make_entry(0, 1);
+                if (v < n && v + 1 < cols) e = make_entry((uint32_t)cdfs[(size_t)r * cols + v],
+                                                          (uint32_t)(cdfs[(size_t)r * cols + v + 1] - cdfs[(size_t)r * cols + v]));
+                entries[t.base + (size_t)r * cols + v] = e;
+            }
+        }
+        tables.push_back(t);
+        return t.base;
+    }
 };
 
 struct pmctf_rans_decoder {
@@ -121,6 +183,10 @@ int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t 
                                            const int32_t *cdf_sizes, const int32_t *offsets) {
     if (!e || !symbols || !indexes || n < 0 || !cdfs || !cdf_sizes || !offsets || cdf_rows <= 0 || cdf_cols <= 2)
         return PMCTF_RANS_EINVAL;
+    for (int r = 0; r < cdf_rows; ++r)
+        if (cdf_sizes[r] < 2 || cdf_sizes[r] > cdf_cols) return PMCTF_RANS_EINVAL;
+    const uint32_t base = e->table_base(cdfs, cdf_rows, cdf_cols, cdf_sizes);
+    if ((uint64_t)e->entries.size() >= kBypassFlag) return PMCTF_RANS_EINVAL;
     const int64_t nparts = (int64_t)e->parts.size();
     const int64_t each = n / nparts;
     for (int64_t pi = 0; pi < nparts; ++pi) {
@@ -132,9 +198,8 @@ int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t 
             const int32_t row = indexes[i];
             if (row < 0) continue;
             if (row >= cdf_rows) return PMCTF_RANS_EINVAL;
-            const int32_t max_value = cdf_sizes[row] - 2;
-            if (max_value < 0 || max_value + 1 >= cdf_cols) return PMCTF_RANS_EINVAL;
-            push_value(steps, cdfs + (size_t)row * cdf_cols, max_value, (int32_t)symbols[i] - offsets[row]);
+            push_value(steps, base + (uint32_t)row * (uint32_t)cdf_cols, cdf_sizes[row] - 2,
+                       (int32_t)symbols[i] - offsets[row]);
         }
     }
     return PMCTF_RANS_OK;
@@ -145,7 +210,7 @@ int pmctf_rans_encoder_flush(pmctf_rans_encoder *e) {
     size_t total = 0, max_size = 0;
     const size_t np = e->parts.size();
     for (size_t i = 0; i < np; ++i) {
-        flush_part(e->parts[i]);
+        flush_part(e->parts[i], e->entries.data());
         const size_t sz = e->parts[i].stream.size();
         total += sz;
         if (i + 1 < np && sz > max_size) max_size = sz;

@@ -156,7 +156,8 @@ class HipEngine:
         # the small-plane kernels of one fill the tails of the other (per-stream LSTM state keeps them apart)
         self.side_streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
         self.multi_stream = False       # measured: no gain (the big kernels already fill every SIMD's register file)
-        self.stats = {"enqueue_s": 0.0, "pair_s": 0.0, "pairs": 0}
+        self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
+        self.profile_host = False
 
     # ------------------------------------------------------------------ packed layers
     def conv(self, p, stride=1, padding=0):

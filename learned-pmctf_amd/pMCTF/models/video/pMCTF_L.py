@@ -199,6 +199,9 @@ class pMCTF(nn.Module):
             luma = code_luma()
             chroma = code_chroma()
         t_enq = time.time() - start
+        if eng.profile_host:
+            torch.cuda.synchronize()
+            eng.stats["gpu_done_s"] += time.time() - start
         done = {k: j.result() for k, j in jobs.items()}
         eng.stats["enqueue_s"] += t_enq
         eng.stats["pair_s"] += time.time() - start
