@@ -57,6 +57,16 @@ int pmctf_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *bi
                           int N, int H, int W, int Cin, int Cout, int KH, int KW,
                           int stride, int pad_h, int pad_w, int act, float slope, void *stream);
 
+/* Explicit-geometry form: output size (Ho,Wo) and top/left padding given by the caller; taps falling outside the
+ * input read zero.  Used to evaluate a stride-1 convolution only at one 2x2 parity class of positions
+ * (stride 2, pad = 1 - parity): the four-step coder needs the last ContextResidual conv and the 1x1 parameter head of
+ * each step only where that step's mask is set (context_fusion_4step.py:127-137,160-189), a quarter of the plane. */
+int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *w_packed, const float *bias_packed,
+                               const float *res1, const float *res2, float *y,
+                               int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                               int stride, int pad_top, int pad_left, int Ho, int Wo, int act, float slope,
+                               void *stream);
+
 /* Same contract for Cin <= 4 (any Cin >= 1), plain OIHW weights on the device: direct
  * convolution on the vector ALU (first layers: 1->16, 1->64, 1->112, 1->128, 2->112, 2->64 ...). */
 int pmctf_conv2d_smallcin_f32(const float *x, const float *w_oihw, const float *bias,
@@ -131,8 +141,11 @@ int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, fl
 /* ---- quantisation + symbol hand-off --------------------------------
  * sym/idx receive one full-size push (int16 symbol, int16 CDF row) in the reference's flattening order
  * (NCHW), exactly what EntropyCoder.encode_with_indexes is given (entropy_models.py:37-40,269-278). */
+/* params: NHWC [N,H,W,2] (params_sub = 0) or, for params computed only at the class-k positions, [N,H/2,W/2,2]
+ * (params_sub = 1; H and W even). */
 int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx, int N,
-                             int H, int W, int k, float log_scale_min, float log_scale_step, void *stream);
+                             int H, int W, int k, int params_sub, float log_scale_min, float log_scale_step,
+                             void *stream);
 int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx, int64_t total,
                        float log_scale_min, float log_scale_step, void *stream);
 int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C, void *stream);

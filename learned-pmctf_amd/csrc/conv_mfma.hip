@@ -603,20 +603,19 @@ extern "C" int pmctf_conv2d_pack_weights(const float *w, const float *bias, int 
     return PMCTF_OK;
 }
 
-extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const float *bp, const float *res1,
-                                     const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
-                                     int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
-                                     void *stream) {
+extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                          const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                                          int act, float slope, void *stream) {
     if (!x || !wp || !bp || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0)
+        KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 || Ho <= 0 || Wo <= 0)
         return PMCTF_EINVAL;
     ConvArgs a;
     a.x = x; a.wp = wp; a.bp = bp; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.S = stride;
-    a.pad_h = pad_h; a.pad_w = pad_w;
-    a.Ho = (H + 2 * pad_h - KH) / stride + 1;
-    a.Wo = (W + 2 * pad_w - KW) / stride + 1;
-    if (a.Ho <= 0 || a.Wo <= 0) return PMCTF_EINVAL;
+    a.pad_h = pad_top; a.pad_w = pad_left;
+    a.Ho = Ho;
+    a.Wo = Wo;
     a.ncb = (Cin + CB - 1) / CB;
     a.act = act; a.slope = slope;
     a.tiles_x = a.tiles_y = 0;
@@ -630,4 +629,15 @@ extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const floa
     case 7: return dispatch_tile<7>(a, MB, st);
     default: return dispatch_tile<8>(a, MB, st);
     }
+}
+
+extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                     const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                     int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                                     void *stream) {
+    if (stride <= 0 || KH <= 0 || KW <= 0) return PMCTF_EINVAL;
+    const int Ho = (H + 2 * pad_h - KH) / stride + 1;
+    const int Wo = (W + 2 * pad_w - KW) / stride + 1;
+    return pmctf_conv2d_nhwc_geom_f32(x, wp, bp, res1, res2, y, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo,
+                                      act, slope, stream);
 }

@@ -167,14 +167,16 @@ __device__ __forceinline__ short sym16(float q) {  // symbols.clamp(-30000, 3000
 // x, so_far: planes [N,H,W]; params NHWC [N,H,W,2] = (scale, mean).  Writes this step's full-size push
 // (int16 symbol + int16 CDF row per element, NCHW order) and x_hat_so_far at the class-k positions.
 __global__ void fourstep_quant_kernel(const float *__restrict__ x, const float *__restrict__ params, float *so_far,
-                                      short *sym, short *idx, int N, int H, int W, int k, float lmin, float step) {
+                                      short *sym, short *idx, int N, int H, int W, int k, int psub, float lmin,
+                                      float step) {
     const long total = (long)N * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int xw = (int)(i % W);
         const int yy = (int)((i / W) % H);
         const int cls = (yy & 1) * 2 + (xw & 1);
         if (cls == k) {
-            const float scale = params[i * 2], mean = params[i * 2 + 1];
+            const long pi = psub ? ((i / ((long)W * H)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xw >> 1) : i;
+            const float scale = params[pi * 2], mean = params[pi * 2 + 1];
             const float res = x[i] - mean;
             const float q = __builtin_rintf(res);
             so_far[i] = q + mean;
@@ -327,11 +329,12 @@ extern "C" int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *c
 }
 
 extern "C" int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx,
-                                        int N, int H, int W, int k, float log_scale_min, float log_scale_step,
-                                        void *stream) {
+                                        int N, int H, int W, int k, int params_sub, float log_scale_min,
+                                        float log_scale_step, void *stream) {
     if (!x || !params || !so_far || !sym || !idx || N <= 0 || H <= 0 || W <= 0 || k < 0 || k > 3) return PMCTF_EINVAL;
+    if (params_sub && ((H | W) & 1)) return PMCTF_EINVAL;
     PM_LAUNCH(fourstep_quant_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
-                       params, so_far, sym, idx, N, H, W, k, log_scale_min, log_scale_step);
+                       params, so_far, sym, idx, N, H, W, k, params_sub, log_scale_min, log_scale_step);
     return launch_ok();
 }
 

@@ -477,8 +477,19 @@ class HipEngine:
             t = self.conv(f"{p}.y_spatial_prior_{step}.0", 1, 1)(so_far.view(N, H, W, 1))
             t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t, res2=c)      # (.. + x) + context
             t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.0", t)
-            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
-            params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
+            if H % 2 == 0 and W % 2 == 0:
+                # this step only consumes its parameters where mask `step` is set: evaluate the last 3x3 conv of the
+                # residual block, its skip and the 1x1 head at that quarter of the positions (identical sums)
+                q = f"{p}.y_spatial_prior_{step}_out.1"
+                o = self.conv(q + ".conv1", 1, 1)(t, act=ACT_LEAKY, slope=0.2)
+                py, px = step >> 1, step & 1
+                tq = ops.empty_nhwc(N, H // 2, W // 2, t.shape[3], self.dev)
+                ew(EW_COPY, as_nchw(t)[:, :, py::2, px::2], out=as_nchw(tq))
+                tq = ops.conv_at_class(self.conv(q + ".conv2", 1, 1), o, step, res1=tq)
+                params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq)
+            else:
+                t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
+                params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
             ops.fourstep_quant(x, params, so_far, stream.sym, stream.idx, stream.take(n, "gauss"), step, self.lmin,
                                self.lstep)
         return so_far

@@ -21,6 +21,7 @@ _SIGS = {
     "pmctf_conv2d_packed_bias_size": (i64, [ci]),
     "pmctf_conv2d_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
     "pmctf_conv2d_nhwc_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
+    "pmctf_conv2d_nhwc_geom_f32": (ci, [vp] * 6 + [ci] * 13 + [cf, vp]),
     "pmctf_conv2d_smallcin_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
     "pmctf_dwconv2d_nhwc_f32": (ci, [vp] * 4 + [ci] * 5 + [vp]),
     "pmctf_flow_warp_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
@@ -34,7 +35,7 @@ _SIGS = {
     "pmctf_pixel_shuffle2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, vp]),
     "pmctf_ffn3_mix_f32": (ci, [vp, vp, i64, ci, vp]),
     "pmctf_lstm_gates_f32": (ci, [vp, vp, vp, vp, i64, ci, ci, vp]),
-    "pmctf_fourstep_quant_f32": (ci, [vp] * 5 + [ci, ci, ci, ci, cf, cf, vp]),
+    "pmctf_fourstep_quant_f32": (ci, [vp] * 5 + [ci, ci, ci, ci, ci, cf, cf, vp]),
     "pmctf_ll_quant_f32": (ci, [vp] * 5 + [i64, cf, cf, vp]),
     "pmctf_z_symbols_f32": (ci, [vp] * 4 + [ci, ci, vp]),
     "pmctf_mv_fourpart_step_f32": (ci, [vp] * 6 + [ci, ci, ci, cf, cf, vp]),

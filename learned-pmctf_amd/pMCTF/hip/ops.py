@@ -249,9 +249,27 @@ def _p16(t, off):
 
 
 def fourstep_quant(x, params, so_far, sym, idx, off, k, lmin, lstep):
+    """params: (N,H,W,2), or (N,H/2,W/2,2) when computed only at the class-k positions"""
     N, _, H, W = x.shape
+    sub = 0 if params.shape[1] == H else 1
+    assert params.shape[1] * (1 + sub) == H and params.shape[2] * (1 + sub) == W
     _lib.check(_lib.hip().pmctf_fourstep_quant_f32(_p(x), _p(params), _p(so_far), _p16(sym, off), _p16(idx, off),
-                                                   N, H, W, k, float(lmin), float(lstep), _stream()), "fourstep_quant")
+                                                   N, H, W, k, sub, float(lmin), float(lstep), _stream()),
+               "fourstep_quant")
+
+
+def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
+    """Evaluate the stride-1 'same' 3x3 conv `conv` only at the positions (2i+py, 2j+px) of parity class cls = 2*py+px:
+    the same sums as the full conv at those positions (stride 2, top/left pad 1-py / 1-px, zeros outside)."""
+    assert not conv.small and conv.stride == 1 and conv.KH == 3 and conv.KW == 3 and conv.pad == (1, 1)
+    N, H, W, Cin = x.shape
+    assert H % 2 == 0 and W % 2 == 0 and Cin == conv.Cin
+    py, px = cls >> 1, cls & 1
+    y = torch.empty((N, H // 2, W // 2, conv.Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H, W,
+                                                     Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2, int(act),
+                                                     float(slope), _stream()), "conv2d_geom")
+    return y
 
 
 def ll_quant(ll, params, sym, idx, off, lmin, lstep):
