@@ -56,6 +56,54 @@ __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *_
     }
 }
 
+
+// Specialised direct conv for the small-Cin layers that dominate this family (3x3 with 1..3 input channels, 1x1 with 2):
+// a thread owns ONE output channel (its K*K*CIN weights + bias live in registers) and walks over pixels; the
+// 256-thread block covers PPP = 256/Cout pixels per pass, stores are contiguous over cout, the input taps of a pixel
+// are wave-broadcast loads.  Same sum order as the generic kernel: acc = bias; for ky: for kx: for ci: fmaf.
+template <int K, int CIN>
+__global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                         const float *__restrict__ bias, const float *res1, const float *res2, float *y,
+                                         int N, int H, int W, int Cout, int S, int ph, int pw, int Ho, int Wo, int act,
+                                         float slope) {
+    const int ppp = 256 / Cout;                 // pixels per pass (Cout <= 256)
+    const int co = threadIdx.x % Cout;
+    const int slot = threadIdx.x / Cout;
+    if (slot >= ppp) return;
+    float wr[K * K * CIN];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(co * CIN + ci) * (K * K) + t];
+    const float b = bias ? bias[co] : 0.0f;
+    const int npix = N * Ho * Wo;               // < 2^31 on this path (checked by the launcher)
+    for (int p = blockIdx.x * ppp + slot; p < npix; p += gridDim.x * ppp) {
+        const int ox = p % Wo;
+        const int r = p / Wo;
+        const int oy = r % Ho;
+        const int n = r / Ho;
+        float acc = b;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * S + ky - ph;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * S + kx - pw;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const float *xp = x + ((size_t)(n * H + iy) * W + ix) * CIN;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc = __builtin_fmaf(xp[ci], wr[(ky * K + kx) * CIN + ci], acc);
+                }
+            }
+        }
+        float v = pm::apply_act(acc, act, slope);
+        const size_t o = (size_t)p * Cout + co;
+        if (res1) v = v + res1[o];
+        if (res2) v = v + res2[o];
+        y[o] = v;
+    }
+}
+
 // depthwise KxK, stride 1, pad K/2; NHWC, channel fastest
 __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                               float *y, int N, int H, int W, int C, int K) {
@@ -200,6 +248,22 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         return PMCTF_EINVAL;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
+    if (KH == KW && Cout <= 256 && (long)N * Ho * Wo < (1L << 31)) {
+        const int ppp = 256 / Cout;
+        long nb = ((long)N * Ho * Wo + ppp - 1) / ppp;
+        if (nb > 16384) nb = 16384;
+        dim3 grid((unsigned)nb), block(256);
+        hipStream_t st = (hipStream_t)stream;
+#define PM_SC(K_, C_)                                                                                               \
+    PM_LAUNCH((conv_smallcin_reg_kernel<K_, C_>), grid, block, 0, st, x, w, bias, res1, res2, y, N, H, W, Cout, stride,  \
+              pad_h, pad_w, Ho, Wo, act, slope);                                                                    \
+    return launch_ok();
+        if (KH == 3 && Cin == 1) { PM_SC(3, 1) }
+        if (KH == 3 && Cin == 2) { PM_SC(3, 2) }
+        if (KH == 3 && Cin == 3) { PM_SC(3, 3) }
+        if (KH == 1 && Cin == 2) { PM_SC(1, 2) }
+#undef PM_SC
+    }
     const size_t smem = (size_t)Cout * Cin * KH * KW * sizeof(float);
     if (smem > 64 * 1024) return PMCTF_EINVAL;
     const long total = (long)N * Ho * Wo * Cout;
