@@ -541,7 +541,11 @@ class Oracle:
         return x + tmp
 
     # ------------------------------------------------------------------ a9: pWave.compress (skip_decoding=True), pWave.py:381-463
-    def pwave_compress(self, coder, x, sideinfo, q_index, qp_scale=None):
+    def pwave_compress(self, coder, x, sideinfo, q_index, qp_scale=None, skip_decoding=True):
+        """skip_decoding=True: LL parameters from the one-shot masked network, symbols pushed plane by plane
+        (pWave.py:413-418).  skip_decoding=False: the reference codes LL position by position
+        (_compress_subband_ar, pWave.py:531-555), i.e. both planes of a position before the next position; the
+        parameters are the same causal function of the same symbols, so only the push ORDER differs (N > 1)."""
         _, num_channels, height, width = sideinfo
         q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
         q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
@@ -564,7 +568,10 @@ class Oracle:
         y_q = torch.round(ll)                   # CompressionModel.process, gaussian_model.py:59-63
         ll_res = y_q - means
         ll_hat = (ll_res.round() + means).round()
-        self.gaussian_encode(ll_res.round(), scales)
+        if skip_decoding:
+            self.gaussian_encode(ll_res.round(), scales)
+        else:
+            self.gaussian_encode(ll_res.round().permute(2, 3, 0, 1).contiguous(), scales.permute(2, 3, 0, 1).contiguous())
         subbands_hat[self.L - 1]["ll"] = ll_hat
         self.ctx_init(list(ll.size()))
         context = self.ctx_forward_one_subband(coder, ll_hat, "ll", self.L - 1)
@@ -596,32 +603,33 @@ class Oracle:
         return x_hat, data, self.trace
 
     # ------------------------------------------------------------------ a8: compress_one_stage, pMCTF_L.py:398-420
-    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, sideinfo, stage_idx=0, q_index=0):
+    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, sideinfo, stage_idx=0, q_index=0,
+                           skip_decoding=True):
         if ischroma:
             mv_hat = self.K.bilinear_down2(mv_hat) / 2
         L_t, H_t, pred, inv = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
-        H_hat, h_bytes, h_trace = self.pwave_compress("hp_coder", H_t, sideinfo, q_index, qp_scale)
+        H_hat, h_bytes, h_trace = self.pwave_compress("hp_coder", H_t, sideinfo, q_index, qp_scale, skip_decoding)
         out = {"L_t": L_t, "H_t": H_t, "H_t_hat": H_hat, "H_bytes": h_bytes, "H_trace": h_trace,
                "L_t_hat": None, "L_bytes": None, "L_trace": None}
         if code_lt:
-            L_hat, l_bytes, l_trace = self.pwave_compress("lp_coder", L_t, sideinfo, q_index)
+            L_hat, l_bytes, l_trace = self.pwave_compress("lp_coder", L_t, sideinfo, q_index, None, skip_decoding)
             out.update({"L_t_hat": L_hat, "L_bytes": l_bytes, "L_trace": l_trace})
         return out
 
     # ------------------------------------------------------------------ a1: encode_one_stage write branch, pMCTF_L.py:553-637
     def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
                          psize=128, skip_decoding=True, stage_idx=0, q_index=0, me_downsample=1):
-        assert skip_decoding and me_downsample == 1, "oracle restates the skip_decoding=True encode path only"
+        assert me_downsample == 1
         ref_y, ref_c = ref_frame
         cur_y, cur_c = cur_frame
         mv = self.compress_mv(ref_y, cur_y, dpb, stage_idx=stage_idx, q_index=q_index)
         files = {"mv": encode_p_bytes(mv["bit_stream"], 0)}
         luma = self.compress_one_stage(ref_y, cur_y, code_lt, mv["mv_hat"], False, [1, 1, pic_height, pic_width],
-                                       stage_idx, q_index)
+                                       stage_idx, q_index, skip_decoding)
         files["H"] = luma["H_bytes"]
         chroma = self.compress_one_stage(ref_c, cur_c, code_lt, mv["mv_hat"], True,
-                                         [1, 2, pic_height // 2, pic_width // 2], stage_idx, q_index)
+                                         [1, 2, pic_height // 2, pic_width // 2], stage_idx, q_index, skip_decoding)
         files["Hc"] = chroma["H_bytes"]
         if code_lt:
             files["L"] = luma["L_bytes"]
@@ -635,6 +643,12 @@ class Oracle:
                 with open(names[k], "wb") as f:
                     f.write(data)
         bits = {k: len(v) * 8.0 for k, v in files.items()}
+        mv_hat_out, mv_feature_out = mv["mv_hat"], mv["mv_feature"]
+        if not skip_decoding:        # pMCTF_L.py:594-612: return what the decoder reconstructs from the files
+            dec = self.decode_one_stage(files, code_lt, dpb, pic_height, pic_width, psize, stage_idx, q_index)
+            mv_hat_out, mv_feature_out = dec["mv_hat"], dec["mv_feature"]
+            luma = dict(luma, H_t_hat=dec["H_t"], L_t_hat=dec.get("L_t"))
+            chroma = dict(chroma, H_t_hat=dec["H_tc"], L_t_hat=dec.get("L_tc"))
         return {
             "L_t": luma["L_t_hat"] if code_lt else luma["L_t"],
             "H_t": luma["H_t_hat"],
@@ -645,9 +659,197 @@ class Oracle:
             "bit_Lc": bits["Lc"] if code_lt else None,
             "bit_Hc": bits["Hc"],
             "bit_ME": bits["mv"],
-            "mv_hat": mv["mv_hat"],
-            "dpb": {"mv_feature": mv["mv_feature"], "ref_mv_y": mv["mv_y_hat"]},
+            "mv_hat": mv_hat_out,
+            "dpb": {"mv_feature": mv_feature_out, "ref_mv_y": mv["mv_y_hat"]},
             "files": files,
+            "enc": {"H_t": luma.get("H_t_enc"), "mv_hat": mv["mv_hat"]},
             "traces": {"mv": mv["trace"], "H": luma["H_trace"], "Hc": chroma["H_trace"],
                        "L": luma["L_trace"], "Lc": chroma["L_trace"]},
         }
+
+
+# ======================================================================================================
+# Decoder restatement: decompress_mv, pWave.decompress, sequential LL AR decode,
+# four-step / four-part decompress.  Mixed into Oracle below.
+# ======================================================================================================
+def get_downsampled_shape(height, width, p):
+    """stream_helper.py:35-38"""
+    new_h = (height + p - 1) // p * p
+    new_w = (width + p - 1) // p * p
+    return int(new_h / p + 0.5), int(new_w / p + 0.5)
+
+
+def decode_p_bytes(data):
+    """stream_helper.py:189-198"""
+    (q,) = struct.unpack(">H", data[:2])
+    (n,) = struct.unpack(">I", data[2:6])
+    return q, data[6:6 + n]
+
+
+def decode_image_bytes(data):
+    """stream_helper.py:210-220"""
+    h, w, c = struct.unpack(">III", data[:12])
+    (n,) = struct.unpack(">I", data[12:16])
+    return h, w, c, data[16:16 + n]
+
+
+class _DecoderMixin:
+    def gaussian_decode(self, scales):
+        """GaussianEncoder.decode_stream, entropy_models.py:280-285"""
+        idx = self.K.build_indexes(self.tables, scales)
+        val = self.ec.decode_stream(idx.reshape(-1), *self.tables.cdf_info())
+        return val.reshape(scales.shape)
+
+    # ---- LL: per-position causal evaluation, context_fusion.py:33-43,140-204 and pWave.py:557-584
+    def ll_sequential_decode(self, coder, N, H, W):
+        p = f"{coder}.context_fusion.{self.L - 1}.ll"
+        sd = self.sd
+        nf = 128
+        cur = torch.zeros(N, 1, H + 2, W + 2)
+        bufs = {k: torch.zeros(N, nf, H + 2, W + 2) for k in ("r0c1", "r0c2", "r1c1", "r1c2", "m2")}
+        w1, b1 = sd[p + ".maskedConv1.weight"], sd[p + ".maskedConv1.bias"]
+        conv = lambda x, name: self.K.conv2d(x, sd[name + ".weight"], sd[name + ".bias"])
+        for h in range(H):
+            for w in range(W):
+                crop = cur[:, :, h:h + 3, w:w + 3]
+                tmp = self.K.conv2d(crop, w1, b1)
+                conv1 = tmp
+                for i in range(2):
+                    q = f"{p}.residualBlocks.{i}"
+                    x = tmp
+                    bufs[f"r{i}c1"][:, :, h + 1:h + 2, w + 1:w + 2] = x
+                    t = conv(bufs[f"r{i}c1"][:, :, h:h + 3, w:w + 3], q + ".conv1")
+                    t = F.leaky_relu(t, 0.2)
+                    bufs[f"r{i}c2"][:, :, h + 1:h + 2, w + 1:w + 2] = t
+                    t = conv(bufs[f"r{i}c2"][:, :, h:h + 3, w:w + 3], q + ".conv2")
+                    tmp = t + x
+                tmp = tmp + conv1
+                bufs["m2"][:, :, h + 1:h + 2, w + 1:w + 2] = tmp
+                t = conv(bufs["m2"][:, :, h:h + 3, w:w + 3], p + ".maskedConv2")
+                t = F.leaky_relu(t, 0.2)
+                t = F.leaky_relu(conv(t, p + ".convs.0"), 0.2)
+                t = F.leaky_relu(conv(t, p + ".convs.1"), 0.2)
+                params = conv(t, p + ".convs.2")
+                scale, mean = params.chunk(2, dim=1)
+                rec = self.gaussian_decode(scale) + mean
+                cur[:, :, h + 1, w + 1] = rec.round()[:, :, 0, 0]
+        return cur[:, :, 1:-1, 1:-1].contiguous()
+
+    def fusion_decompress(self, p, context, prev_subband):
+        """ContextFusionFourStep.decompress, context_fusion_4step.py:196-249"""
+        if prev_subband is not None:
+            prev = F.interpolate(prev_subband, scale_factor=2, mode="nearest")
+            prev = self.conv(p + ".lower_level_subband.1", prev, padding=1)
+            context = torch.cat((context, prev), dim=1)
+        context = self.conv(p + ".conv1_context", context, padding=1)
+        context = self.context_residual(p + ".y_hierarchical_prior_enc.0", context)
+        context = self.context_residual(p + ".y_hierarchical_prior_enc.1", context)
+        hp = self.depth_conv_block(p + ".y_hierarchical_prior_out", context)
+        scales, means = hp.chunk(2, dim=1)
+        _, _, H, W = scales.size()
+        masks = self.masks4(H, W)
+        q = self.gaussian_decode(scales * masks[0])
+        so_far = (q + means) * masks[0]
+        for step in (1, 2, 3):
+            t = self.conv(f"{p}.y_spatial_prior_{step}.0", so_far, padding=1)
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t)
+            t = t + context
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.0", t)
+            t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
+            params = self.conv(f"{p}.y_spatial_prior_{step}_out.2", t)
+            scales, means = params.chunk(2, dim=1)
+            q = self.gaussian_decode(scales * masks[step])
+            so_far = so_far + (q + means) * masks[step]
+        return so_far
+
+    def pwave_decompress(self, coder, data, padding, q_index, qp_scale=None):
+        """pWave.decompress, pWave.py:467-529"""
+        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+        if qp_scale is not None:
+            q_scale = q_scale * qp_scale
+            q_scale_ll = q_scale_ll * qp_scale
+        height, width, num_channel, bit_stream = decode_image_bytes(data)
+        self.ec = entropy.EntropyCoder()
+        self.ec.set_stream(bit_stream)
+        new_h = (height + padding - 1) // padding * padding
+        new_w = (width + padding - 1) // padding * padding
+        sh, sw = new_h // (2 ** self.L), new_w // (2 ** self.L)
+        ll_rec = self.ll_sequential_decode(coder, num_channel, sh, sw)
+        ret = {lvl: {} for lvl in range(self.L)}
+        ret[self.L - 1]["ll"] = ll_rec
+        self.ctx_init(list(ll_rec.size()))
+        context = self.ctx_forward_one_subband(coder, ll_rec, "ll", self.L - 1)
+        for lvl in range(self.L - 1, -1, -1):
+            for sidx, sb in enumerate(["lh", "hl", "hh"]):
+                ctx = context.chunk(3, dim=1)[sidx]
+                prev = ret[lvl + 1][sb] if lvl < self.L - 1 else None
+                s_hat = self.fusion_decompress(f"{coder}.context_fusion.{lvl}.{sb}", ctx, prev)
+                ret[lvl][sb] = s_hat
+                context = self.ctx_forward_one_subband(coder, s_hat, sb, lvl)
+        rec = {lvl: {} for lvl in range(self.L)}
+        for lvl in range(self.L - 1, -1, -1):
+            for sb in (["ll", "lh", "hl", "hh"] if lvl == self.L - 1 else ["lh", "hl", "hh"]):
+                rec[lvl][sb] = ret[lvl][sb] / (q_scale_ll if sb == "ll" else q_scale)
+        out = None
+        for lvl in range(self.L - 1, -1, -1):
+            out = self.backward_lift_2d(coder, rec[lvl])
+            if lvl > 0:
+                rec[lvl - 1]["ll"] = out
+        return self.post_process(coder, out / 256.0) * 256.0
+
+    def decompress_four_part_prior(self, s, common_params):
+        """MVCoderQuad.decompress_four_part_prior, four_part_prior.py:217-280"""
+        quant_step, scales, means = common_params.chunk(3, 1)
+        quant_step = torch.max(quant_step, torch.ones_like(quant_step) * 0.5)
+        _, _, H, W = means.size()
+        m = self.masks4(H, W)
+        sc = scales.chunk(4, 1)
+        mu = means.chunk(4, 1)
+        perms = ((0, 1, 2, 3), (3, 2, 1, 0), (2, 3, 0, 1), (1, 0, 3, 2))
+        so_far = None
+        for t in range(4):
+            if t > 0:
+                out = self.mv_spatial_prior(s, t, torch.cat((so_far, common_params), dim=1))
+                sc, mu = out[:4], out[4:]
+            pm = perms[t]
+            scales_r = sc[0] * m[pm[0]] + sc[1] * m[pm[1]] + sc[2] * m[pm[2]] + sc[3] * m[pm[3]]
+            y_q_r = self.gaussian_decode(scales_r)
+            cur = torch.cat([(y_q_r + mu[g]) * m[pm[g]] for g in range(4)], dim=1)
+            so_far = cur if so_far is None else so_far + cur
+        return so_far * quant_step
+
+    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0):
+        """pMCTF.decompress_mv, pMCTF_L.py:497-523"""
+        s = min(self.num_me_stages - 1, stage_idx)
+        _, q_dec = self.get_mv_y_q(q_index, s)
+        self.ec = entropy.EntropyCoder()
+        self.ec.set_stream(string)
+        zh, zw = get_downsampled_shape(int(height), int(width), 64)
+        be = self.bit_est[s]
+        idx = be.build_indexes((1, 64, zh, zw))
+        z_hat = self.ec.decode_stream(idx.reshape(-1), *be.cdf_info()).reshape(idx.shape).float()
+        mv_params = self.mv_prior_param_decoder(z_hat, dpb, s)
+        mv_y_hat = self.decompress_four_part_prior(s, mv_params)
+        mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        return {"mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat}
+
+    def decode_one_stage(self, files, code_lt, dpb, pic_height, pic_width, psize=128, stage_idx=0, q_index=0):
+        """decode branch of encode_one_stage (pMCTF_L.py:594-612): files = the dict written by the encoder"""
+        _, string = decode_p_bytes(files["mv"])
+        ph = (pic_height + psize - 1) // psize * psize
+        pw = (pic_width + psize - 1) // psize * psize
+        mv = self.decompress_mv(string, ph, pw, dpb, stage_idx, q_index)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        out = {"mv_hat": mv["mv_hat"], "mv_feature": mv["mv_feature"], "mv_y_hat": mv["mv_y_hat"],
+               "H_t": self.pwave_decompress("hp_coder", files["H"], psize, q_index, qp_scale),
+               "H_tc": self.pwave_decompress("hp_coder", files["Hc"], psize // 2, q_index, qp_scale)}
+        if code_lt:
+            out["L_t"] = self.pwave_decompress("lp_coder", files["L"], psize, q_index)
+            out["L_tc"] = self.pwave_decompress("lp_coder", files["Lc"], psize // 2, q_index)
+        return out
+
+
+for _n, _f in list(vars(_DecoderMixin).items()):
+    if callable(_f) and not _n.startswith("__"):
+        setattr(Oracle, _n, _f)

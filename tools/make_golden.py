@@ -184,6 +184,20 @@ def main():
             for i, (ry, rc, _) in enumerate(rec_frames):
                 out[f"gop.rec{i}.y"] = ry.numpy()
 
+        # ---- one pair with the real decoder in the loop (skip_decoding=False, pMCTF_L.py:594-612) ------------
+        with tempfile.TemporaryDirectory() as td:
+            trace.clear()
+            dpb = {"mv_feature": None, "ref_mv_y": None}
+            r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
+                                     pic_height=H, pic_width=W, stage_idx=0, code_lt=True, psize=128,
+                                     skip_decoding=False, dpb=dpb, q_index=3)
+            for name in sorted(os.listdir(td)):
+                out[f"dec.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
+            for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+                out[f"dec.{k}"] = r[k].numpy().copy()
+            out["dec.mv_feature"] = r["dpb"]["mv_feature"].numpy().copy()
+            out["dec.bits"] = np.array([r["bit_H"], r["bit_L"], r["bit_ME"]], np.float64)
+
     path = os.path.join(args.out, f"reference_{W}x{H}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}.meta.json"), "w"), indent=1)
