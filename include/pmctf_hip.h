@@ -146,13 +146,46 @@ int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, fl
 int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx, int N,
                              int H, int W, int k, int params_sub, float log_scale_min, float log_scale_step,
                              void *stream);
+/* planes > 0: push in the order of the sequential coder (_compress_subband_ar, pWave.py:531-555): position-major,
+ * plane-minor (total = planes * positions); planes = 0: plane-major NCHW order of the one-shot path (pWave.py:418). */
 int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx, int64_t total,
-                       float log_scale_min, float log_scale_step, void *stream);
+                       int planes, float log_scale_min, float log_scale_step, void *stream);
 int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C, void *stream);
 int pmctf_mv_fourpart_step_f32(const float *y, const float *common, const float *sp, float *so_far, int16_t *sym,
                                int16_t *idx, int H, int W, int t, float log_scale_min, float log_scale_step,
                                void *stream);
 int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat, int64_t HW, void *stream);
+
+/* ---- decoder side ----------------------------------------------------------------
+ * LL subband: pWave._decompress_subband_ar + ContextFusionSubband.forward_sequential (pWave.py:557-584,
+ * context_fusion.py:140-204) as one persistent workgroup that evaluates the causal masked-conv network per
+ * position and decodes the position's symbols from the rANS stream inside the kernel.
+ *   w_packed: pmctf_ll_ar_pack_weights() output on the device; stream_words: the rANS payload (after the 1-byte
+ *   header) as little-endian uint32 on the device; (x0,pos0) / state_out[0..1]: Rans64 state and next-word index
+ *   before / after (state_out[2] != 0: stream exhausted); cdf/sizes/offsets: the Laplace tables on the device;
+ *   ll_out [N][H][W]; scratch_zeroed: pmctf_ll_ar_scratch_floats(N,H,W) floats, zero-filled.  N <= 2. */
+int64_t pmctf_ll_ar_packed_size(void);
+int pmctf_ll_ar_pack_weights(const float *w_a, const float *b_a, const float *const *w_b, const float *const *b_b,
+                             const float *w_p0, const float *b_p0, const float *w_p1, const float *b_p1,
+                             const float *w_p2, const float *b_p2, float *out);      /* HOST pointers */
+int64_t pmctf_ll_ar_scratch_floats(int N, int H, int W);
+int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *stream_words, int64_t n_words, uint64_t x0,
+                           int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets, int cdf_cols,
+                           float log_scale_min, float log_scale_step, float *ll_out, float *scratch_zeroed, int N, int H,
+                           int W, uint64_t *state_out, void *stream);
+/* ContextFusionFourStep.decompress (context_fusion_4step.py:196-249): CDF rows handed to decode_stream for step k
+ * (0 off the mask), then x_hat = (q + mean) on the mask.  params as in pmctf_fourstep_quant_f32. */
+int pmctf_fourstep_indexes_f32(const float *params, int16_t *idx, int N, int H, int W, int k, int params_sub,
+                               float log_scale_min, float log_scale_step, void *stream);
+int pmctf_fourstep_dequant_f32(const int16_t *sym, const float *params, float *so_far, int N, int H, int W, int k,
+                               int params_sub, void *stream);
+/* MVCoderQuad.decompress_four_part_prior (four_part_prior.py:217-280), step t; idx/sym: [16][H*W] */
+int pmctf_mv_fourpart_indexes_f32(const float *common, const float *sp, int16_t *idx, int H, int W, int t,
+                                  float log_scale_min, float log_scale_step, void *stream);
+int pmctf_mv_fourpart_dequant_f32(const int16_t *sym, const float *common, const float *sp, float *so_far, int H, int W,
+                                  int t, void *stream);
+/* decoded int16 symbols [C][HW] -> float NHWC [HW][C] (mv_z_hat, pMCTF_L.py:504-505) */
+int pmctf_sym_to_nhwc_f32(const int16_t *sym, float *out, int HW, int C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,11 @@ int pmctf_rans_decoder_decode_stream(pmctf_rans_decoder *d, const int16_t *index
                                      int cdf_rows, int cdf_cols, const int32_t *cdf_sizes, const int32_t *offsets,
                                      int16_t *out);
 
+/* Hand-over of a single-stream decoder's state to/from the in-kernel LL decoder (include/pmctf_hip.h,
+ * pmctf_ll_ar_decode_f32): Rans64 state x and the index of the next 32-bit payload word. */
+int pmctf_rans_decoder_get_state(const pmctf_rans_decoder *d, uint64_t *x, int64_t *word_pos);
+int pmctf_rans_decoder_set_state(pmctf_rans_decoder *d, uint64_t x, int64_t word_pos);
+
 /* pmf_to_quantized_cdf(pmf, precision) -> cdf[n+1]                    ops.cpp:24-82 */
 int pmctf_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf);
 

@@ -1,0 +1,419 @@
+// decode_ops.hip — decoder-side kernels of the pMCTF path.
+//
+//  * pmctf_ll_ar_decode_f32: the sequential, per-position autoregressive decode of the LL subband
+//    (pWave._decompress_subband_ar + ContextFusionSubband.forward_sequential, pWave.py:557-584,
+//    context_fusion.py:140-204) as ONE persistent workgroup: per position it evaluates the masked-conv network
+//    on the causal neighbourhood (activations of earlier positions are kept in HBM/L2-resident NHWC buffers),
+//    decodes the position's symbols from the rANS stream IN the kernel (the stream order is raster order, so
+//    nothing else can run ahead) and writes ll_hat.  The entropy-coder state is handed in and out so that the
+//    host decoder continues with the following subbands.
+//  * index / dequantisation kernels of the four-step and four-part decompress
+//    (context_fusion_4step.py:196-249, four_part_prior.py:217-280).
+//
+// Arithmetic: PM-F32.  Each output channel is one sequential fmaf chain in the spec's order (16-channel chunks,
+// taps in raster order, channel ascending); masked (zero-weight) and out-of-image taps are skipped, which leaves
+// the chain's value unchanged, so the parameters equal those of the encoder's one-shot masked convolutions bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pm_device_math.h"
+#include "launch.h"
+#include "../../include/pmctf_hip.h"
+
+namespace {
+
+inline int launch_ok() { return pm_launch_status(); }
+inline unsigned grid_for(long n, int bs = 256, unsigned cap = 16384) {
+    long b = (n + bs - 1) / bs;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+constexpr int NF = 128;           // features of ContextFusionSubband
+constexpr int TB = 5;             // causal taps of a type-B 3x3 mask: (0,0)(0,1)(0,2)(1,0)(1,1)
+
+struct LLArgs {
+    const float *w;               // packed weights, see pmctf_ll_ar_pack_weights
+    const uint32_t *stream;       // rANS words (after the 1-byte stream header), device copy
+    long n_words;
+    unsigned long long x0;        // decoder state on entry
+    long pos0;                    // next word index on entry
+    const int32_t *cdf;           // [256][cols]
+    const int32_t *sizes, *offsets;
+    int cols;
+    float lmin, lstep;
+    float *ll_out;                // [N][H][W]
+    float *bufs;                  // 5 activation buffers [N][(H+1)][(W+2)][NF], zero-initialised by the caller
+    int N, H, W;
+    unsigned long long *state_out;  // [0] = x, [1] = word position, [2] = error flag
+};
+
+// offsets (in floats) inside the packed weight blob
+constexpr long W_L0 = 0;                                  // [4 taps][NF]      maskedConv1 (type A, Cin = 1)
+constexpr long B_L0 = W_L0 + 4 * NF;                      // [NF]
+constexpr long W_MB = B_L0 + NF;                          // 5 type-B layers, each [8 chunks][5 taps][16][NF] + bias [NF]
+constexpr long SZ_MB = (long)8 * TB * 16 * NF + NF;
+constexpr long W_P0 = W_MB + 5 * SZ_MB;                   // convs.0: [NF k][NF] + bias
+constexpr long W_P1 = W_P0 + (long)NF * NF + NF;          // convs.1
+constexpr long W_P2 = W_P1 + (long)NF * NF + NF;          // convs.2: [NF k][2] + bias[2]
+constexpr long W_TOTAL = W_P2 + NF * 2 + 2;
+
+__device__ __forceinline__ float leaky02(float v) { return v > 0.0f ? v : v * 0.2f; }
+
+// type-B masked 3x3, 128 -> 128, at one position: act[t][ch] in LDS (t = causal tap), one output channel per thread
+__device__ __forceinline__ float masked_b(const float *__restrict__ wl, const float *act, int co) {
+    float acc = wl[(long)8 * TB * 16 * NF + co];           // bias
+    const float *wp = wl + co;
+#pragma unroll 1
+    for (int cb = 0; cb < 8; ++cb) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const float *a = act + t * NF + cb * 16;
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) acc = __builtin_fmaf(a[ci], wp[(long)((cb * TB + t) * 16 + ci) * NF], acc);
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float dense128(const float *__restrict__ wl, const float *act, int co, int nout) {
+    float acc = wl[(long)NF * nout + co];
+    const float *wp = wl + co;
+#pragma unroll 1
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) acc = __builtin_fmaf(act[cb * 16 + ci], wp[(long)(cb * 16 + ci) * nout], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void ll_ar_decode_kernel(LLArgs a) {
+    __shared__ float act[2][TB * NF];     // per plane: gathered causal activations of the current layer
+    __shared__ float vec[2][NF];          // per plane: a 128-vector passed between 1x1 layers
+    __shared__ float prm[2][2];           // per plane: (scale, mean)
+    __shared__ float newval[2];
+    const int tid = threadIdx.x;
+    const int plane = tid >> 7;
+    const int co = tid & (NF - 1);
+    const bool live = plane < a.N;
+    const int PW = a.W + 2, PH = a.H + 1;                 // buffers carry one zero row on top and one zero column each side
+    const long bufsz = (long)a.N * PH * PW * NF;
+    float *buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = a.bufs + i * bufsz + (long)(live ? plane : 0) * PH * PW * NF;
+    float *cur = a.ll_out + (long)(live ? plane : 0) * a.H * a.W;
+    const float *w = a.w;
+    // L0 weights in registers
+    const float w00 = w[W_L0 + 0 * NF + co], w01 = w[W_L0 + 1 * NF + co], w02 = w[W_L0 + 2 * NF + co],
+                w10 = w[W_L0 + 3 * NF + co], b0 = w[B_L0 + co];
+    unsigned long long x = a.x0;
+    long pos = a.pos0;
+    int err = 0;
+
+    for (int h = 0; h < a.H; ++h) {
+        for (int wq = 0; wq < a.W; ++wq) {
+            // ---- maskedConv1 (type A) on the decoded plane
+            float v00 = 0.f, v01 = 0.f, v02 = 0.f, v10 = 0.f;
+            if (live) {
+                if (h > 0) {
+                    if (wq > 0) v00 = cur[(long)(h - 1) * a.W + wq - 1];
+                    v01 = cur[(long)(h - 1) * a.W + wq];
+                    if (wq + 1 < a.W) v02 = cur[(long)(h - 1) * a.W + wq + 1];
+                }
+                if (wq > 0) v10 = cur[(long)h * a.W + wq - 1];
+            }
+            float t = b0;
+            t = __builtin_fmaf(v00, w00, t);
+            t = __builtin_fmaf(v01, w01, t);
+            t = __builtin_fmaf(v02, w02, t);
+            t = __builtin_fmaf(v10, w10, t);
+            const float conv1 = t;
+            // position (h, wq) lives at buffer row h+1, column wq+1
+            const long cpos = ((long)(h + 1) * PW + (wq + 1)) * NF + co;
+            const long up = cpos - (long)PW * NF;
+            float xin = conv1;
+            // ---- two masked residual blocks, then maskedConv2: five type-B layers over buffers 0..4
+#pragma unroll 1
+            for (int layer = 0; layer < 5; ++layer) {
+                float *bb = buf[layer];
+                if (live) {
+                    bb[cpos] = xin;
+                    act[plane][0 * NF + co] = bb[up - NF];
+                    act[plane][1 * NF + co] = bb[up];
+                    act[plane][2 * NF + co] = bb[up + NF];
+                    act[plane][3 * NF + co] = bb[cpos - NF];
+                    act[plane][4 * NF + co] = xin;
+                }
+                __syncthreads();
+                float o = 0.f;
+                if (live) o = masked_b(w + W_MB + layer * SZ_MB, act[plane], co);
+                __syncthreads();
+                if (layer == 0 || layer == 2) {            // conv1 of a residual block: leaky, keep block input in xres
+                    vec[plane][co] = xin;                   // (own slot: no race)
+                    xin = leaky02(o);
+                } else if (layer == 1 || layer == 3) {      // conv2 of a residual block: + block input
+                    xin = o + vec[plane][co];
+                    if (layer == 3) xin = xin + conv1;      // x = x + conv1 before maskedConv2 (context_fusion.py:119)
+                } else {
+                    xin = leaky02(o);                       // maskedConv2 + lrelu
+                }
+            }
+            // ---- 1x1 head: 128 -> 128 -> 128 -> 2
+            if (live) act[plane][co] = xin;
+            __syncthreads();
+            float p0 = 0.f;
+            if (live) p0 = leaky02(dense128(w + W_P0, act[plane], co, NF));
+            __syncthreads();
+            if (live) act[plane][co] = p0;
+            __syncthreads();
+            float p1 = 0.f;
+            if (live) p1 = leaky02(dense128(w + W_P1, act[plane], co, NF));
+            __syncthreads();
+            if (live) act[plane][co] = p1;
+            __syncthreads();
+            if (live && co < 2) prm[plane][co] = dense128(w + W_P2, act[plane], co, 2);
+            __syncthreads();
+            // ---- entropy decode (wave 0, uniform): plane 0 then plane 1 (pWave.py:566-575 with B planes)
+            if (tid < 64) {
+                for (int pl = 0; pl < a.N; ++pl) {
+                    float s = prm[pl][0];
+                    const float mean = prm[pl][1];
+                    s = s < 1e-5f ? 1e-5f : s;
+                    float iv = (pm::logf_(s) - a.lmin) / a.lstep;
+                    iv = iv < 0.0f ? 0.0f : iv;
+                    iv = iv > 255.0f ? 255.0f : iv;
+                    const int row = (int)iv;
+                    const int32_t *cd = a.cdf + (long)row * a.cols;
+                    const int size = a.sizes[row];
+                    const int max_value = size - 2;
+                    const unsigned cum = (unsigned)(x & 0xFFFFull);
+                    // s = (number of entries <= cum) - 1, entries 0..size-1
+                    int cnt = 0;
+                    for (int base = 0; base < size; base += 64) {
+                        const int i = base + tid;
+                        const bool le = i < size && (unsigned)cd[i] <= cum;
+                        cnt += __builtin_popcountll(__ballot(le));
+                    }
+                    const int sidx = cnt - 1;
+                    const unsigned start = (unsigned)cd[sidx], freq = (unsigned)(cd[sidx + 1] - cd[sidx]);
+                    x = (unsigned long long)freq * (x >> 16) + (x & 0xFFFFull) - start;
+                    if (x < (1ull << 31)) {
+                        if (pos < a.n_words) x = (x << 32) | a.stream[pos]; else err = 1;
+                        ++pos;
+                    }
+                    int value = sidx;
+                    if (value == max_value) {               // bypass digits (rans.cpp:303-325)
+                        auto bits4 = [&]() -> int {
+                            const int val = (int)(x & 15ull);
+                            x >>= 4;
+                            if (x < (1ull << 31)) {
+                                if (pos < a.n_words) x = (x << 32) | a.stream[pos]; else err = 1;
+                                ++pos;
+                            }
+                            return val;
+                        };
+                        int val = bits4();
+                        int n_bypass = val;
+                        while (val == 15) { val = bits4(); n_bypass += val; }
+                        int raw = 0;
+                        for (int j = 0; j < n_bypass; ++j) raw |= bits4() << (j * 4);
+                        value = raw >> 1;
+                        if (raw & 1) value = -value - 1; else value += max_value;
+                    }
+                    const float q = (float)(short)(value + a.offsets[row]);
+                    if (tid == 0) newval[pl] = __builtin_rintf(q + mean);
+                }
+            }
+            __syncthreads();
+            if (live && co == 0) cur[(long)h * a.W + wq] = newval[plane];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        a.state_out[0] = x;
+        a.state_out[1] = (unsigned long long)pos;
+        a.state_out[2] = (unsigned long long)err;
+    }
+}
+
+// four-step decompress: CDF rows of step k (0 off the mask), then x_hat at the mask positions
+__device__ __forceinline__ int scale_index(float s, float lmin, float step) {
+    s = s < 1e-5f ? 1e-5f : s;
+    float v = (pm::logf_(s) - lmin) / step;
+    v = v < 0.0f ? 0.0f : v;
+    v = v > 255.0f ? 255.0f : v;
+    return (int)v;
+}
+
+__global__ void fourstep_indexes_kernel(const float *__restrict__ params, short *idx, int N, int H, int W, int k,
+                                        int psub, float lmin, float step) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xw = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        short r = 0;
+        if ((yy & 1) * 2 + (xw & 1) == k) {
+            const long pi = psub ? ((i / ((long)W * H)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xw >> 1) : i;
+            r = (short)scale_index(params[pi * 2], lmin, step);
+        }
+        idx[i] = r;
+    }
+}
+
+__global__ void fourstep_dequant_kernel(const short *__restrict__ sym, const float *__restrict__ params, float *so_far,
+                                        int N, int H, int W, int k, int psub) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xw = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        if ((yy & 1) * 2 + (xw & 1) == k) {
+            const long pi = psub ? ((i / ((long)W * H)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xw >> 1) : i;
+            so_far[i] = (float)sym[i] + params[pi * 2 + 1];
+        } else if (k == 0) {
+            so_far[i] = 0.0f;
+        }
+    }
+}
+
+__constant__ int MVD_PERM[4][4] = {{0, 1, 2, 3}, {3, 2, 1, 0}, {2, 3, 0, 1}, {1, 0, 3, 2}};
+
+__global__ void mv_fourpart_indexes_kernel(const float *__restrict__ common, const float *__restrict__ sp, short *idx,
+                                           int H, int W, int t, float lmin, float step) {
+    const long HW = (long)H * W;
+    const long total = HW * 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i / HW);
+        const long p = i - (long)cc * HW;
+        const int xw = (int)(p % W), yy = (int)(p / W);
+        const int cls = (yy & 1) * 2 + (xw & 1);
+        int g = 0;
+        for (int q = 0; q < 4; ++q) if (MVD_PERM[t][q] == cls) g = q;
+        const float scale = t == 0 ? common[p * 192 + 64 + g * 16 + cc] : sp[p * 128 + g * 16 + cc];
+        idx[i] = (short)scale_index(scale, lmin, step);
+    }
+}
+
+__global__ void mv_fourpart_dequant_kernel(const short *__restrict__ sym, const float *__restrict__ common,
+                                           const float *__restrict__ sp, float *so_far, int H, int W, int t) {
+    const long HW = (long)H * W;
+    const long total = HW * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 63);
+        const long p = i >> 6;
+        const int xw = (int)(p % W), yy = (int)(p / W);
+        const int cls = (yy & 1) * 2 + (xw & 1);
+        const int g = c >> 4, cc = c & 15;
+        if (MVD_PERM[t][g] == cls) {
+            const float mean = t == 0 ? common[p * 192 + 128 + c] : sp[p * 128 + 64 + g * 16 + cc];
+            so_far[i] = (float)sym[(long)cc * HW + p] + mean;
+        } else if (t == 0) {
+            so_far[i] = 0.0f;
+        }
+    }
+}
+
+// int16 NCHW symbols -> float NHWC (MV hyper latent z_hat after host decode)
+__global__ void sym_to_nhwc_kernel(const short *__restrict__ sym, float *out, int HW, int C) {
+    const long total = (long)HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        out[i] = (float)sym[(long)c * HW + p];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t pmctf_ll_ar_packed_size(void) { return W_TOTAL; }
+
+// HOST: pack the (already masked) filters of ContextFusionSubband into the layout of the decode kernel.
+//  w_a [128][1][3][3], b_a[128]; w_b[5] = {res0.conv1, res0.conv2, res1.conv1, res1.conv2, maskedConv2}: [128][128][3][3] + bias;
+//  w_p0, w_p1: [128][128] (1x1), w_p2: [2][128]
+extern "C" int pmctf_ll_ar_pack_weights(const float *w_a, const float *b_a, const float *const *w_b, const float *const *b_b,
+                                        const float *w_p0, const float *b_p0, const float *w_p1, const float *b_p1,
+                                        const float *w_p2, const float *b_p2, float *out) {
+    if (!w_a || !b_a || !w_b || !b_b || !w_p0 || !b_p0 || !w_p1 || !b_p1 || !w_p2 || !b_p2 || !out) return PMCTF_EINVAL;
+    static const int TA[4][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}};
+    static const int TBT[5][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 1}};
+    for (int t = 0; t < 4; ++t)
+        for (int co = 0; co < NF; ++co) out[W_L0 + t * NF + co] = w_a[co * 9 + TA[t][0] * 3 + TA[t][1]];
+    for (int co = 0; co < NF; ++co) out[B_L0 + co] = b_a[co];
+    for (int l = 0; l < 5; ++l) {
+        float *o = out + W_MB + l * SZ_MB;
+        for (int cb = 0; cb < 8; ++cb)
+            for (int t = 0; t < TB; ++t)
+                for (int ci = 0; ci < 16; ++ci)
+                    for (int co = 0; co < NF; ++co)
+                        o[(long)((cb * TB + t) * 16 + ci) * NF + co] =
+                            w_b[l][((long)co * NF + cb * 16 + ci) * 9 + TBT[t][0] * 3 + TBT[t][1]];
+        for (int co = 0; co < NF; ++co) o[(long)8 * TB * 16 * NF + co] = b_b[l][co];
+    }
+    const float *wp[2] = {w_p0, w_p1};
+    const float *bp[2] = {b_p0, b_p1};
+    const long offs[2] = {W_P0, W_P1};
+    for (int l = 0; l < 2; ++l) {
+        for (int k = 0; k < NF; ++k)
+            for (int co = 0; co < NF; ++co) out[offs[l] + (long)k * NF + co] = wp[l][(long)co * NF + k];
+        for (int co = 0; co < NF; ++co) out[offs[l] + (long)NF * NF + co] = bp[l][co];
+    }
+    for (int k = 0; k < NF; ++k)
+        for (int co = 0; co < 2; ++co) out[W_P2 + (long)k * 2 + co] = w_p2[(long)co * NF + k];
+    out[W_P2 + NF * 2 + 0] = b_p2[0];
+    out[W_P2 + NF * 2 + 1] = b_p2[1];
+    return PMCTF_OK;
+}
+
+extern "C" int64_t pmctf_ll_ar_scratch_floats(int N, int H, int W) { return (int64_t)5 * N * (H + 1) * (W + 2) * NF; }
+
+extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *stream_words, int64_t n_words, uint64_t x0,
+                                      int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets,
+                                      int cdf_cols, float log_scale_min, float log_scale_step, float *ll_out,
+                                      float *scratch_zeroed, int N, int H, int W, uint64_t *state_out, void *stream) {
+    if (!w_packed || !stream_words || !cdf || !sizes || !offsets || !ll_out || !scratch_zeroed || !state_out || N < 1 ||
+        N > 2 || H < 1 || W < 1 || n_words < 0 || cdf_cols < 3)
+        return PMCTF_EINVAL;
+    LLArgs a;
+    a.w = w_packed; a.stream = stream_words; a.n_words = n_words; a.x0 = x0; a.pos0 = pos0;
+    a.cdf = cdf; a.sizes = sizes; a.offsets = offsets; a.cols = cdf_cols;
+    a.lmin = log_scale_min; a.lstep = log_scale_step;
+    a.ll_out = ll_out; a.bufs = scratch_zeroed; a.N = N; a.H = H; a.W = W;
+    a.state_out = (unsigned long long *)state_out;
+    PM_LAUNCH(ll_ar_decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_ok();
+}
+
+extern "C" int pmctf_fourstep_indexes_f32(const float *params, int16_t *idx, int N, int H, int W, int k, int params_sub,
+                                          float log_scale_min, float log_scale_step, void *stream) {
+    if (!params || !idx || N <= 0 || H <= 0 || W <= 0 || k < 0 || k > 3 || (params_sub && ((H | W) & 1))) return PMCTF_EINVAL;
+    PM_LAUNCH(fourstep_indexes_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, params, idx, N,
+              H, W, k, params_sub, log_scale_min, log_scale_step);
+    return launch_ok();
+}
+
+extern "C" int pmctf_fourstep_dequant_f32(const int16_t *sym, const float *params, float *so_far, int N, int H, int W,
+                                          int k, int params_sub, void *stream) {
+    if (!sym || !params || !so_far || N <= 0 || H <= 0 || W <= 0 || k < 0 || k > 3 || (params_sub && ((H | W) & 1)))
+        return PMCTF_EINVAL;
+    PM_LAUNCH(fourstep_dequant_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, sym, params,
+              so_far, N, H, W, k, params_sub);
+    return launch_ok();
+}
+
+extern "C" int pmctf_mv_fourpart_indexes_f32(const float *common, const float *sp, int16_t *idx, int H, int W, int t,
+                                             float log_scale_min, float log_scale_step, void *stream) {
+    if (!common || !idx || H <= 0 || W <= 0 || t < 0 || t > 3 || (t > 0 && !sp)) return PMCTF_EINVAL;
+    PM_LAUNCH(mv_fourpart_indexes_kernel, dim3(grid_for((long)H * W * 16)), dim3(256), 0, (hipStream_t)stream, common, sp,
+              idx, H, W, t, log_scale_min, log_scale_step);
+    return launch_ok();
+}
+
+extern "C" int pmctf_mv_fourpart_dequant_f32(const int16_t *sym, const float *common, const float *sp, float *so_far,
+                                             int H, int W, int t, void *stream) {
+    if (!sym || !common || !so_far || H <= 0 || W <= 0 || t < 0 || t > 3 || (t > 0 && !sp)) return PMCTF_EINVAL;
+    PM_LAUNCH(mv_fourpart_dequant_kernel, dim3(grid_for((long)H * W * 64)), dim3(256), 0, (hipStream_t)stream, sym, common,
+              sp, so_far, H, W, t);
+    return launch_ok();
+}
+
+extern "C" int pmctf_sym_to_nhwc_f32(const int16_t *sym, float *out, int HW, int C, void *stream) {
+    if (!sym || !out || HW <= 0 || C <= 0) return PMCTF_EINVAL;
+    PM_LAUNCH(sym_to_nhwc_kernel, dim3(grid_for((long)HW * C)), dim3(256), 0, (hipStream_t)stream, sym, out, HW, C);
+    return launch_ok();
+}

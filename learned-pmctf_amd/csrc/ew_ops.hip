@@ -193,14 +193,16 @@ __global__ void fourstep_quant_kernel(const float *__restrict__ x, const float *
 // LL subband (pWave.py:408-418 with gaussian_model.py:59-63): ll is already round(clamp(ll*QP_ll));
 // res = ll - mean; sym = round(res); ll_hat = round(round(res) + mean)
 __global__ void ll_quant_kernel(const float *__restrict__ ll, const float *__restrict__ params, float *ll_hat,
-                                short *sym, short *idx, long total, float lmin, float step) {
+                                short *sym, short *idx, long total, int planes, float lmin, float step) {
+    const long npos = planes > 0 ? total / planes : total;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long o = planes > 0 ? (i % npos) * planes + i / npos : i;     // position-major for the sequential coder
         const float scale = params[i * 2], mean = params[i * 2 + 1];
         const float res = __builtin_rintf(ll[i]) - mean;
         const float q = __builtin_rintf(res);
         ll_hat[i] = __builtin_rintf(q + mean);
-        sym[i] = sym16(q);
-        idx[i] = (short)scale_index(scale, lmin, step);
+        sym[o] = sym16(q);
+        idx[o] = (short)scale_index(scale, lmin, step);
     }
 }
 
@@ -339,10 +341,11 @@ extern "C" int pmctf_fourstep_quant_f32(const float *x, const float *params, flo
 }
 
 extern "C" int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx,
-                                  int64_t total, float log_scale_min, float log_scale_step, void *stream) {
-    if (!ll || !params || !ll_hat || !sym || !idx || total <= 0) return PMCTF_EINVAL;
+                                  int64_t total, int planes, float log_scale_min, float log_scale_step, void *stream) {
+    if (!ll || !params || !ll_hat || !sym || !idx || total <= 0 || planes < 0 || (planes > 0 && total % planes))
+        return PMCTF_EINVAL;
     PM_LAUNCH(ll_quant_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ll, params, ll_hat, sym,
-                       idx, (long)total, log_scale_min, log_scale_step);
+                       idx, (long)total, planes, log_scale_min, log_scale_step);
     return launch_ok();
 }
 

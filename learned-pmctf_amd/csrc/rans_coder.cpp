@@ -352,6 +352,22 @@ int pmctf_rans_decoder_decode_stream(pmctf_rans_decoder *d, const int16_t *index
     return PMCTF_RANS_OK;
 }
 
+int pmctf_rans_decoder_get_state(const pmctf_rans_decoder *d, uint64_t *x, int64_t *word_pos) {
+    if (!d || !x || !word_pos || d->parts.size() != 1 || !d->parts[0].ptr) return PMCTF_RANS_EINVAL;
+    *x = d->parts[0].x;
+    *word_pos = (int64_t)(d->parts[0].ptr - d->parts[0].buf.data());
+    return PMCTF_RANS_OK;
+}
+
+int pmctf_rans_decoder_set_state(pmctf_rans_decoder *d, uint64_t x, int64_t word_pos) {
+    if (!d || d->parts.size() != 1 || !d->parts[0].ptr || word_pos < 2 ||
+        word_pos > (int64_t)(d->parts[0].end - d->parts[0].buf.data()) + 1)
+        return PMCTF_RANS_EINVAL;
+    d->parts[0].x = x;
+    d->parts[0].ptr = d->parts[0].buf.data() + word_pos;
+    return PMCTF_RANS_OK;
+}
+
 int pmctf_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf) {
     if (!pmf || !cdf || n <= 0 || precision <= 0 || precision > 16) return PMCTF_RANS_EINVAL;
     cdf[0] = 0;

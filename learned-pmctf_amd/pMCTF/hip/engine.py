@@ -544,8 +544,9 @@ class HipEngine:
             n += 3 * 4 * N * (H >> (lvl + 1)) * (W >> (lvl + 1))
         return n
 
-    def pwave_compress(self, coder, x, q_index, qp_scale=None):
-        """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream)."""
+    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False):
+        """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream).  ar_order: LL symbols in the sequential coder's
+        order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555)."""
         q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
         q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
         if qp_scale is not None:
@@ -564,7 +565,7 @@ class HipEngine:
         llq = ew(EW_ROUND_CLAMP_MULS, ll, alpha=q_scale_ll, beta=clip)
         params = self.context_fusion_ll(coder, llq)
         ll_hat = ops.ll_quant(llq, params, stream.sym, stream.idx, stream.take(llq.numel(), "gauss"), self.lmin,
-                              self.lstep)
+                              self.lstep, ar_order)
         hat[self.L - 1]["ll"] = ll_hat
         lstm_state = self.ctx_init(N, ll.shape[2], ll.shape[3])
         context = self.ctx_forward_one_subband(coder, lstm_state, ll_hat, "ll", self.L - 1)
@@ -590,16 +591,215 @@ class HipEngine:
         return x_hat, stream
 
     # ------------------------------------------------------------------ a8 compress_one_stage (pMCTF_L.py:398-420)
-    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0):
+    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0, ar_order=False):
         if ischroma:
             mv_hat = ops.bilinear_down2(mv_hat, 2.0)
         L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
-        H_hat, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale)
+        H_hat, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, ar_order)
         out = {"L_t": L_t, "H_t": H_t, "H_t_hat": H_hat, "H_stream": h_stream, "L_t_hat": None, "L_stream": None}
         if code_lt:
-            out["L_t_hat"], out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index)
+            out["L_t_hat"], out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index, None, ar_order)
         return out
+
+
+    # =================================================================================================
+    # Decoder: pMCTF.decompress_mv / pWave.decompress on the GPU, entropy decoding on the host
+    # (libpmctf_rans.so) except for the sequential LL subband, which is decoded inside one persistent kernel.
+    # =================================================================================================
+    def _dev_tables(self, name):
+        t = self._dev_tab.get(name) if hasattr(self, "_dev_tab") else None
+        if t is None:
+            if not hasattr(self, "_dev_tab"):
+                self._dev_tab = {}
+            cdf, sizes, offsets = self.tables[name]
+            t = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (cdf, sizes, offsets))
+            torch.cuda.synchronize(self.dev)
+            self._dev_tab[name] = t
+        return t
+
+    def _ll_weights(self, coder):
+        if not hasattr(self, "_llw"):
+            self._llw = {}
+        w = self._llw.get(coder)
+        if w is None:
+            p = f"{coder}.context_fusion.{self.L - 1}.ll"
+            g = lambda k: np.ascontiguousarray(self.sd[p + k].numpy(), dtype=np.float32)
+            names = [".residualBlocks.0.conv1", ".residualBlocks.0.conv2", ".residualBlocks.1.conv1",
+                     ".residualBlocks.1.conv2", ".maskedConv2"]
+            wb = [g(n + ".weight") for n in names]
+            bb = [g(n + ".bias") for n in names]
+            PF = C.POINTER(C.c_float)
+            wb_p = (C.c_void_p * 5)(*[a.ctypes.data for a in wb])
+            bb_p = (C.c_void_p * 5)(*[a.ctypes.data for a in bb])
+            L = _lib.hip()
+            out = np.empty(L.pmctf_ll_ar_packed_size(), np.float32)
+            keep = [g(".maskedConv1.weight"), g(".maskedConv1.bias"), g(".convs.0.weight"), g(".convs.0.bias"),
+                    g(".convs.1.weight"), g(".convs.1.bias"), g(".convs.2.weight"), g(".convs.2.bias")]
+            _lib.check(L.pmctf_ll_ar_pack_weights(keep[0].ctypes.data, keep[1].ctypes.data, C.addressof(wb_p),
+                                                  C.addressof(bb_p), keep[2].ctypes.data, keep[3].ctypes.data,
+                                                  keep[4].ctypes.data, keep[5].ctypes.data, keep[6].ctypes.data,
+                                                  keep[7].ctypes.data, out.ctypes.data), "ll_ar_pack_weights")
+            w = torch.from_numpy(out).to(self.dev)
+            torch.cuda.synchronize(self.dev)
+            self._llw[coder] = w
+        return w
+
+    def _decode(self, dec, idx_dev, table):
+        """device int16 CDF rows -> host range decoder -> device int16 symbols"""
+        return torch.from_numpy(dec.decode(idx_dev.cpu().numpy(), table)).to(self.dev)
+
+    def ll_ar_decode(self, coder, dec, N, H, W):
+        L = _lib.hip()
+        w = self._ll_weights(coder)
+        cdf, sizes, offsets = self._dev_tables("gauss")
+        words = torch.from_numpy(dec.words.copy()).to(self.dev)
+        x, pos = dec.get_state()
+        ll = torch.zeros((N, 1, H, W), dtype=torch.float32, device=self.dev)
+        scratch = torch.zeros(L.pmctf_ll_ar_scratch_floats(N, H, W), dtype=torch.float32, device=self.dev)
+        state = torch.zeros(3, dtype=torch.int64, device=self.dev)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.pmctf_ll_ar_decode_f32(vp(w), vp(words), words.numel(), C.c_uint64(x), pos, vp(cdf), vp(sizes),
+                                            vp(offsets), cdf.shape[1], float(self.lmin), float(self.lstep), vp(ll),
+                                            vp(scratch), N, H, W, vp(state), ops._stream()), "ll_ar_decode")
+        st = state.cpu().numpy()
+        if st[2] != 0:
+            raise ValueError("LL decode ran past the end of the bitstream")
+        dec.set_state(int(np.uint64(st[0])), int(st[1]))
+        return ll
+
+    def fusion_decompress(self, p, ctx, prev, dec, N, H, W):
+        """ContextFusionFourStep.decompress (context_fusion_4step.py:196-249)"""
+        if prev is not None:
+            up = ops.nearest_up2(prev.view(N, H // 2, W // 2, 1))
+            prevc = self.conv(p + ".lower_level_subband.1", 1, 1)(up)
+            ctx = self.cat_channels(ctx, prevc)
+        c = self.conv(p + ".conv1_context", 1, 1)(ctx)
+        c = self.context_residual(p + ".y_hierarchical_prior_enc.0", c)
+        c = self.context_residual(p + ".y_hierarchical_prior_enc.1", c)
+        params = self.depth_conv_block(p + ".y_hierarchical_prior_out", c)
+        so_far = torch.empty((N, 1, H, W), dtype=torch.float32, device=self.dev)
+        for step in range(4):
+            if step > 0:
+                t = self.conv(f"{p}.y_spatial_prior_{step}.0", 1, 1)(so_far.view(N, H, W, 1))
+                t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t, res2=c)
+                t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.0", t)
+                if H % 2 == 0 and W % 2 == 0:
+                    q = f"{p}.y_spatial_prior_{step}_out.1"
+                    o = self.conv(q + ".conv1", 1, 1)(t, act=ACT_LEAKY, slope=0.2)
+                    py, px = step >> 1, step & 1
+                    tq = ops.empty_nhwc(N, H // 2, W // 2, t.shape[3], self.dev)
+                    ew(EW_COPY, as_nchw(t)[:, :, py::2, px::2], out=as_nchw(tq))
+                    tq = ops.conv_at_class(self.conv(q + ".conv2", 1, 1), o, step, res1=tq)
+                    params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq)
+                else:
+                    t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
+                    params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
+            idx = ops.fourstep_indexes(params, N, H, W, step, self.lmin, self.lstep)
+            sym = self._decode(dec, idx, "gauss")
+            ops.fourstep_dequant(sym, params, so_far, step)
+        return so_far
+
+    def pwave_decompress(self, coder, data, padding, q_index, qp_scale=None):
+        """pWave.decompress (pWave.py:467-529) from the bytes of one bitstream file -> x_hat plane (N,1,Hp,Wp)"""
+        import struct
+        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+        if qp_scale is not None:
+            q_scale = q_scale * qp_scale
+            q_scale_ll = q_scale_ll * qp_scale
+        q_scale, q_scale_ll = float(q_scale), float(q_scale_ll)
+        height, width, N = struct.unpack(">III", data[:12])
+        (n,) = struct.unpack(">I", data[12:16])
+        dec = HostDecoder(self.tables, data[16:16 + n])
+        new_h = (height + padding - 1) // padding * padding
+        new_w = (width + padding - 1) // padding * padding
+        sh, sw = new_h >> self.L, new_w >> self.L
+        ll_rec = self.ll_ar_decode(coder, dec, N, sh, sw)
+        hat = {lvl: {} for lvl in range(self.L)}
+        hat[self.L - 1]["ll"] = ll_rec
+        lstm_state = self.ctx_init(N, sh, sw)
+        context = self.ctx_forward_one_subband(coder, lstm_state, ll_rec, "ll", self.L - 1)
+        for lvl in range(self.L - 1, -1, -1):
+            h, w = new_h >> (lvl + 1), new_w >> (lvl + 1)
+            for sidx, sb in enumerate(("lh", "hl", "hh")):
+                ctx = ops.empty_nhwc(N, h, w, 1, self.dev)
+                ew(EW_COPY, as_nchw(context)[:, sidx:sidx + 1], out=as_nchw(ctx))
+                prev = hat[lvl + 1][sb] if lvl < self.L - 1 else None
+                s_hat = self.fusion_decompress(f"{coder}.context_fusion.{lvl}.{sb}", ctx, prev, dec, N, h, w)
+                hat[lvl][sb] = s_hat
+                context = self.ctx_forward_one_subband(coder, lstm_state, s_hat, sb, lvl)
+        rec_ll = ew(EW_DIVS, hat[self.L - 1]["ll"], alpha=q_scale_ll)
+        out = None
+        for lvl in range(self.L - 1, -1, -1):
+            sbs = {"ll": rec_ll}
+            for sb in ("lh", "hl", "hh"):
+                sbs[sb] = ew(EW_DIVS, hat[lvl][sb], alpha=q_scale)
+            out = self.backward_lift_2d(coder, sbs)
+            rec_ll = out
+        return self.post_process(coder, out, 256.0, 256.0)
+
+    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0):
+        """pMCTF.decompress_mv (pMCTF_L.py:497-523)"""
+        s = min(self.num_me_stages - 1, stage_idx)
+        _, q_dec = self.get_mv_y_q(q_index, s)
+        dec = HostDecoder(self.tables, string)
+        p = 64
+        hz = int(((int(height) + p - 1) // p * p) / p + 0.5)
+        wz = int(((int(width) + p - 1) // p * p) / p + 0.5)
+        idx = np.repeat(np.arange(64, dtype=np.int16), hz * wz)
+        zsym = torch.from_numpy(dec.decode(idx, f"z{s}")).to(self.dev)
+        z_hat = ops.sym_to_nhwc(zsym, hz, wz, 64)
+        common = self.mv_prior_param_decoder(z_hat, self.to_nhwc_input(dpb["ref_mv_y"]), s)
+        hy, wy = common.shape[1], common.shape[2]
+        so_far = torch.empty((1, hy, wy, 64), dtype=torch.float32, device=self.dev)
+        sp = None
+        for t in range(4):
+            if t > 0:
+                x = self.conv(f"mv_y_spatial_prior_adaptor_{t}.{s}")(self.cat_channels(so_far, common))
+                for i in range(3):
+                    x = self.depth_conv_block(f"mv_y_spatial_prior.{s}.{i}", x)
+                sp = x
+            idx_d = ops.mv_fourpart_indexes(common, sp, hy, wy, t, self.lmin, self.lstep)
+            sym = self._decode(dec, idx_d, "gauss")
+            ops.mv_fourpart_dequant(sym, common, sp, so_far, t)
+        mv_y_hat = ops.mv_dequant(so_far, common)
+        mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        return {"mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat}
+
+
+class HostDecoder:
+    """One bitstream on the host range decoder (libpmctf_rans.so), sharing the engine's CDF tables."""
+
+    def __init__(self, tables, stream):
+        self.R = _lib.rans()
+        self.tables = tables
+        self.h = self.R.pmctf_rans_decoder_create(1)
+        buf = np.frombuffer(bytes(stream), dtype=np.uint8).copy()
+        _lib.check(self.R.pmctf_rans_decoder_set_stream(self.h, buf.ctypes.data, buf.size), "rans set_stream")
+        self.words = np.frombuffer(buf[1:].tobytes(), dtype=np.uint32)       # payload words after the flag byte
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.R.pmctf_rans_decoder_destroy(self.h)
+            self.h = None
+
+    def decode(self, idx, table):
+        idx = np.ascontiguousarray(idx, dtype=np.int16).reshape(-1)
+        cdf, sizes, offsets = self.tables[table]
+        out = np.empty(idx.size, np.int16)
+        _lib.check(self.R.pmctf_rans_decoder_decode_stream(self.h, idx.ctypes.data, idx.size, cdf.ctypes.data,
+                                                           cdf.shape[0], cdf.shape[1], sizes.ctypes.data,
+                                                           offsets.ctypes.data, out.ctypes.data), "rans decode_stream")
+        return out
+
+    def get_state(self):
+        x, pos = C.c_uint64(0), C.c_int64(0)
+        _lib.check(self.R.pmctf_rans_decoder_get_state(self.h, C.byref(x), C.byref(pos)), "rans get_state")
+        return x.value, pos.value
+
+    def set_state(self, x, pos):
+        _lib.check(self.R.pmctf_rans_decoder_set_state(self.h, C.c_uint64(x), pos), "rans set_state")
 
 
 def as_nchw_ew(op, t_nhwc, alpha=0.0, beta=0.0):

@@ -36,7 +36,16 @@ _SIGS = {
     "pmctf_ffn3_mix_f32": (ci, [vp, vp, i64, ci, vp]),
     "pmctf_lstm_gates_f32": (ci, [vp, vp, vp, vp, i64, ci, ci, vp]),
     "pmctf_fourstep_quant_f32": (ci, [vp] * 5 + [ci, ci, ci, ci, ci, cf, cf, vp]),
-    "pmctf_ll_quant_f32": (ci, [vp] * 5 + [i64, cf, cf, vp]),
+    "pmctf_ll_quant_f32": (ci, [vp] * 5 + [i64, ci, cf, cf, vp]),
+    "pmctf_ll_ar_packed_size": (i64, []),
+    "pmctf_ll_ar_pack_weights": (ci, [vp] * 11),
+    "pmctf_ll_ar_scratch_floats": (i64, [ci, ci, ci]),
+    "pmctf_ll_ar_decode_f32": (ci, [vp, vp, i64, C.c_uint64, i64, vp, vp, vp, ci, cf, cf, vp, vp, ci, ci, ci, vp, vp]),
+    "pmctf_fourstep_indexes_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp]),
+    "pmctf_fourstep_dequant_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "pmctf_mv_fourpart_indexes_f32": (ci, [vp, vp, vp, ci, ci, ci, cf, cf, vp]),
+    "pmctf_mv_fourpart_dequant_f32": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
+    "pmctf_sym_to_nhwc_f32": (ci, [vp, vp, ci, ci, vp]),
     "pmctf_z_symbols_f32": (ci, [vp] * 4 + [ci, ci, vp]),
     "pmctf_mv_fourpart_step_f32": (ci, [vp] * 6 + [ci, ci, ci, cf, cf, vp]),
     "pmctf_mv_dequant_f32": (ci, [vp, vp, vp, i64, vp]),
@@ -57,6 +66,8 @@ _RANS_SIGS = {
     "pmctf_rans_decoder_set_stream": (ci, [vp, vp, i64]),
     "pmctf_rans_decoder_decode_stream": (ci, [vp, vp, i64, vp, ci, ci, vp, vp, vp]),
     "pmctf_pmf_to_quantized_cdf": (ci, [vp, ci, ci, vp]),
+    "pmctf_rans_decoder_get_state": (ci, [vp, vp, vp]),
+    "pmctf_rans_decoder_set_state": (ci, [vp, C.c_uint64, i64]),
 }
 _rans = None
 

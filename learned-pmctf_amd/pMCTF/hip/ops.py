@@ -272,11 +272,52 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
     return y
 
 
-def ll_quant(ll, params, sym, idx, off, lmin, lstep):
+def ll_quant(ll, params, sym, idx, off, lmin, lstep, ar_order=False):
+    """ar_order: symbols in the sequential coder's order (position-major over the N planes)"""
     ll_hat = torch.empty_like(ll)
     _lib.check(_lib.hip().pmctf_ll_quant_f32(_p(ll), _p(params), _p(ll_hat), _p16(sym, off), _p16(idx, off),
-                                             ll.numel(), float(lmin), float(lstep), _stream()), "ll_quant")
+                                             ll.numel(), ll.shape[0] if ar_order else 0, float(lmin), float(lstep),
+                                             _stream()), "ll_quant")
     return ll_hat
+
+
+def _pi16(t):
+    assert t.is_cuda and t.dtype == torch.int16 and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def fourstep_indexes(params, N, H, W, k, lmin, lstep):
+    idx = torch.empty(N * H * W, dtype=torch.int16, device=params.device)
+    sub = 0 if params.shape[1] == H else 1
+    _lib.check(_lib.hip().pmctf_fourstep_indexes_f32(_p(params), _pi16(idx), N, H, W, k, sub, float(lmin), float(lstep),
+                                                     _stream()), "fourstep_indexes")
+    return idx
+
+
+def fourstep_dequant(sym, params, so_far, k):
+    N, _, H, W = so_far.shape
+    sub = 0 if params.shape[1] == H else 1
+    _lib.check(_lib.hip().pmctf_fourstep_dequant_f32(_pi16(sym), _p(params), _p(so_far), N, H, W, k, sub, _stream()),
+               "fourstep_dequant")
+
+
+def mv_fourpart_indexes(common, sp, H, W, t, lmin, lstep):
+    idx = torch.empty(16 * H * W, dtype=torch.int16, device=common.device)
+    _lib.check(_lib.hip().pmctf_mv_fourpart_indexes_f32(_p(common), _p(sp), _pi16(idx), H, W, t, float(lmin),
+                                                        float(lstep), _stream()), "mv_fourpart_indexes")
+    return idx
+
+
+def mv_fourpart_dequant(sym, common, sp, so_far, t):
+    _, H, W, _ = so_far.shape
+    _lib.check(_lib.hip().pmctf_mv_fourpart_dequant_f32(_pi16(sym), _p(common), _p(sp), _p(so_far), H, W, t, _stream()),
+               "mv_fourpart_dequant")
+
+
+def sym_to_nhwc(sym, H, W, Cc):
+    out = torch.empty((1, H, W, Cc), dtype=torch.float32, device=sym.device)
+    _lib.check(_lib.hip().pmctf_sym_to_nhwc_f32(_pi16(sym), _p(out), H * W, Cc, _stream()), "sym_to_nhwc")
+    return out
 
 
 def z_symbols(z, sym, idx, off):

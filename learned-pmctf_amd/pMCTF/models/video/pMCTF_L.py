@@ -7,10 +7,9 @@ test_pMCTF_flex.py runs unchanged.  All tensor arithmetic of the encode path run
 gfx950 kernels (pMCTF.hip.engine.HipEngine -> libpmctf_hip.so); the range coder is libpmctf_rans.so
 on host threads.  There is no CPU fallback: without a GPU and the built libraries the calls raise.
 
-Implemented: the write-stream encode branch with skip_decoding=True (pMCTF_L.py:553-637) and
-inverse_MCTF.  Not implemented in this round (raise NotImplementedError): the estimate-only branch
-(output_path=None; broken in the reference itself), skip_decoding=False (real decoder),
-me_downsample > 1, training forward.
+Implemented: the write-stream encode branch (pMCTF_L.py:553-637) with skip_decoding True or False (real decoder:
+decompress_mv, decompress_one_stage), inverse_MCTF.  Not implemented (raise NotImplementedError): the estimate-only
+branch (output_path=None; broken in the reference itself), me_downsample > 1, training forward.
 """
 import os
 import os.path as osp
@@ -25,7 +24,7 @@ from pMCTF.hip.engine import HipEngine
 from pMCTF.layers.modules import (DepthConvBlock, ME_Spynet, MvDec, MvEnc, TemporalLifting, get_hyper_dec_model,
                                   get_hyper_enc_model)
 from pMCTF.models.pWave import pWave
-from pMCTF.utils.stream_helper import image_header, mv_header
+from pMCTF.utils.stream_helper import decode_p, image_header, mv_header
 
 
 class MVCoderQuad(nn.Module):
@@ -126,6 +125,31 @@ class pMCTF(nn.Module):
         c = lambda t: t.contiguous()
         return self.engine().forward_MCTF(c(ref_frame), c(cur_frame), c(mv_hat), stage_idx)
 
+    @torch.no_grad()
+    def decompress_mv(self, string, dtype, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
+        """pMCTF_L.py:497-523 — returns mv_hat (1,2,H,W) and the MV decoder contexts (logical NCHW views)"""
+        if me_downsample != 1:
+            raise NotImplementedError("me_downsample > 1")
+        d = self.engine().decompress_mv(string, height, width, dpb, stage_idx=stage_idx, q_index=q_index)
+        return {"mv_hat": d["mv_hat"], "mv_feature": d["mv_feature"].permute(0, 3, 1, 2),
+                "mv_y_hat": d["mv_y_hat"].permute(0, 3, 1, 2)}
+
+    @torch.no_grad()
+    def decompress_one_stage(self, file_name, code_lt, ischroma, psize=128, q_index=0, stage_idx=0):
+        """pMCTF_L.py:422-439"""
+        from pMCTF.hip.engine import get_curr_q
+        eng = self.engine()
+        qp_scale = get_curr_q(eng.sd[f"hp_q_scale.{stage_idx}"], q_index) if self.quant_stage else None
+        pad = psize // 2 if ischroma else psize
+        with open(file_name, "rb") as f:
+            H_t = eng.pwave_decompress("hp_coder", f.read(), pad, q_index, qp_scale)
+        L_t = None
+        if code_lt:
+            file_name_l = file_name.replace(osp.basename(file_name), "0_C_main.bin" if ischroma else "0_main.bin")
+            with open(file_name_l, "rb") as f:
+                L_t = {"x_hat": eng.pwave_decompress("lp_coder", f.read(), pad, q_index)}
+        return {"L_t": L_t, "H_t": {"x_hat": H_t}}
+
     def forward(self, *args, **kwargs):
         raise NotImplementedError("estimate-mode / training forward is outside the encode hot path of this build")
 
@@ -138,9 +162,6 @@ class pMCTF(nn.Module):
         if output_path is None:
             raise NotImplementedError("estimate-only branch (output_path=None) is not part of this build "
                                       "(it raises KeyError in the reference as well)")
-        if not skip_decoding:
-            raise NotImplementedError("real decoding (skip_decoding=False) is the next scope item; "
-                                      "run with --skip_decoding 1")
         if me_downsample != 1:
             raise NotImplementedError("me_downsample > 1")
         eng = self.engine()
@@ -159,7 +180,7 @@ class pMCTF(nn.Module):
         ry, cy, rc, cc = c(ref_y), c(cur_y), c(ref_chroma), c(cur_chroma)
 
         def code_luma():
-            r = eng.compress_one_stage(ry, cy, code_lt, mv_hat, False, stage_idx, q_index)
+            r = eng.compress_one_stage(ry, cy, code_lt, mv_hat, False, stage_idx, q_index, not skip_decoding)
             jobs["H"] = eng.coder.submit(r["H_stream"], eng.tables,
                                          lambda n: image_header(pic_height, pic_width, 1, n), output_path, keep)
             if code_lt:
@@ -169,7 +190,7 @@ class pMCTF(nn.Module):
             return r
 
         def code_chroma():
-            r = eng.compress_one_stage(rc, cc, code_lt, mv_hat, True, stage_idx, q_index)
+            r = eng.compress_one_stage(rc, cc, code_lt, mv_hat, True, stage_idx, q_index, not skip_decoding)
             jobs["Hc"] = eng.coder.submit(r["H_stream"], eng.tables,
                                           lambda n: image_header(pic_height // 2, pic_width // 2, 2, n), file_name_c,
                                           keep)
@@ -208,6 +229,25 @@ class pMCTF(nn.Module):
         eng.stats["pairs"] += 1
         encoding_time = time.time() - start
         bits = {k: v[0] * 8.0 for k, v in done.items()}
+        decoding_time = 0
+        mv_feature = mv["mv_feature"]
+        if not skip_decoding:
+            # pMCTF_L.py:594-612: hand back what the decoder reconstructs from the files just written
+            t0 = time.time()
+            mv_y_q_index, string = decode_p(mv_out)
+            decoded = self.decompress_mv(string, ref_y.dtype, ref_y.size(2), ref_y.size(3), dpb, stage_idx=stage_idx,
+                                         q_index=q_index)
+            mv_hat = decoded["mv_hat"]
+            mv_feature = decoded["mv_feature"].permute(0, 2, 3, 1)
+            out_dec = self.decompress_one_stage(output_path, code_lt, ischroma=False, psize=psize, q_index=q_index,
+                                                stage_idx=stage_idx)
+            out_dec_c = self.decompress_one_stage(file_name_c, code_lt, ischroma=True, psize=psize, q_index=q_index,
+                                                  stage_idx=stage_idx)
+            torch.cuda.synchronize()
+            decoding_time = time.time() - t0
+            luma = dict(luma, H_t_hat=out_dec["H_t"]["x_hat"], L_t_hat=out_dec["L_t"]["x_hat"] if code_lt else None)
+            chroma = dict(chroma, H_t_hat=out_dec_c["H_t"]["x_hat"],
+                          L_t_hat=out_dec_c["L_t"]["x_hat"] if code_lt else None)
         result = {
             "L_t": luma["L_t_hat"] if code_lt else luma["L_t"],
             "H_t": luma["H_t_hat"],
@@ -219,8 +259,8 @@ class pMCTF(nn.Module):
             "bit_Hc": bits["Hc"],
             "bit_ME": bits["mv"],
             "mv_hat": mv_hat,
-            "dpb": {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)},
-            "decoding_time": 0,
+            "dpb": {"mv_feature": mv_feature.permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)},
+            "decoding_time": decoding_time,
             "encoding_time": encoding_time,
         }
         if keep:

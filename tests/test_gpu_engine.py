@@ -118,3 +118,28 @@ def test_gop4_files_bits_psnr(setup):
     # the fixtures come from the real reference: bpp bit-exact (file sizes), PSNR within 1e-4 dB
     assert enc["bits"] == list(g["gop.bits"])
     assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
+
+
+def test_decoder_round_trip_and_oracle(setup):
+    """skip_decoding=False: bitstreams written by the HIP encoder are decoded by the HIP decoder (LL subband inside the
+    persistent AR kernel) to exactly the encoder's reconstruction, and everything equals the oracle's decoder."""
+    import os
+    net, orc = setup
+    fr = frames(W, H, 2)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    with tempfile.TemporaryDirectory() as td:
+        enc = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                   pic_height=H, skip_decoding=True, stage_idx=0, q_index=3)
+        r = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                 pic_height=H, skip_decoding=False, stage_idx=0, q_index=3)
+    o = orc.encode_one_stage(fr[0], fr[1], True, dpb, pic_width=W, pic_height=H, q_index=3, skip_decoding=False)
+    for k in o["files"]:
+        assert r["files"][k] == o["files"][k], f"file {k} differs from the oracle (decoder-order stream)"
+    for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+        assert_same(r[k], enc[k], f"decoded {k} vs encoder reconstruction")
+        assert_same(r[k], o[k], f"decoded {k} vs oracle decoder")
+    assert_same(r["dpb"]["mv_feature"], o["dpb"]["mv_feature"], "decoded mv_feature")
+    g = golden()   # the real reference with its decoder in the loop: same sizes, reconstruction within fp noise
+    assert np.abs(r["H_t"].cpu().numpy() - g["dec.H_t"]).max() < 2e-3
+    assert r["bit_ME"] == g["dec.bits"][2]
