@@ -107,8 +107,8 @@ def main():
     PH, PW = frames[0][0].shape[2], frames[0][0].shape[3]
     sub_h, sub_w = PH // 2, PW // 2
 
-    def dominant(conv, x):   # ContextResidual 3x3 112->112 on a level-0 luma subband
-        return (not conv.small) and conv.Cin == 112 and conv.Cout == 112 and conv.KH == 3 and \
+    def dominant(conv, x, stride):   # ContextResidual 3x3 112->112 on a level-0 luma subband (full-resolution form)
+        return stride == 1 and (not conv.small) and conv.Cin == 112 and conv.Cout == 112 and conv.KH == 3 and \
             x.shape[0] == 1 and x.shape[1] == sub_h and x.shape[2] == sub_w
 
     tmp = tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_")

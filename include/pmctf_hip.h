@@ -43,6 +43,13 @@ int pmctf_conv2d_pack_weights(const float *w_oihw, const float *bias, int Cout, 
                               float *w_packed, float *bias_packed);
 int64_t pmctf_conv2d_packed_bias_size(int Cout);
 
+/* Launch-shape tuning of pmctf_conv2d_nhwc*_f32 (never changes results, only how the work is cut into workgroups).
+ * Names (also read once from the environment as PMCTF_CONV_<NAME>): "WAVE" 0/1 wave-private kernel, "NT" force 1/2/4
+ * pixel segments per wave, "MSPLIT_PX" planes with at most this many output pixels run one cout tile per workgroup,
+ * "SPLIT" 0/1 cut the partial last round of 8x32 tiles into 4x16 tiles, "BIGPX" smallest plane given 8x32 tiles,
+ * "V1"/"V2" force the single-buffer / pipelined kernel. */
+int pmctf_conv2d_set_option(const char *name, long value);
+
 /* nn.Conv2d forward (groups=1, zero padding), optionally fused with what follows it
  * in the reference: y = act(conv(x) + bias) [+ res1] [+ res2].
  *   reference: F.conv2d behind every nn.Conv2d on the path, e.g.

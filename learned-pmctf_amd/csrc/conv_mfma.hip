@@ -13,6 +13,7 @@
 // (every workgroup reads the same <=0.5 MB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "pm_device_math.h"
@@ -33,6 +34,9 @@ struct ConvArgs {
     int N, H, W, Cin, Cout, KH, KW, S, pad_h, pad_w, Ho, Wo;
     int tiles_x, tiles_y, ncb, act;
     float slope;
+    // mtp: cout tiles per packed M-block (the weight layout); a workgroup handles MT <= mtp of them, blockIdx.z
+    // enumerates groups of MT tiles.  [oy_base, oy_end): output rows this launch covers.
+    int mtp, oy_base, oy_end;
 };
 
 // MT: cout tiles per workgroup, NT: pixel tiles per wave, TW16: 16-pixel segments per tile row.
@@ -46,9 +50,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
     const int n = blockIdx.y;
-    const int mb = blockIdx.z;
+    const int mtile0 = blockIdx.z * MT;                 // first cout tile of this workgroup
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy0 = a.oy_base + ty * TH, ox0 = tx * TW;
     const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
     const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
     const int taps = a.KH * a.KW;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // accumulators start at the bias: acc = bias[co]
     f32x4 acc[MT][NT];
     {
-        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 b = *(const f32x4 *)(bp + mt * 16);
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         boff[nt] = ((r * a.S) * LW + (c16 * 16 + (lane & 15)) * a.S) * CP + (lane >> 4);
     }
     const int E = LH * LW * 4;  // float4 units per chunk
-    const float *wbase = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;
+    const int wstride = a.mtp * 256;
+    const float *wbase = a.wp + (size_t)mb * a.ncb * taps * wstride + mtin * 256 + lane * 4;
 
     for (int cb = 0; cb < a.ncb; ++cb) {
         __syncthreads();  // previous chunk fully consumed
@@ -92,13 +98,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         __syncthreads();
         const int crem = a.Cin - cb * CB;
         const int ksteps = crem >= CB ? 4 : (crem + 3) >> 2;
-        const float *wc = wbase + (size_t)cb * taps * (MT * 256);
+        const float *wc = wbase + (size_t)cb * taps * wstride;
         int tap = 0;
         for (int ky = 0; ky < a.KH; ++ky) {
             for (int kx = 0; kx < a.KW; ++kx, ++tap) {
                 f32x4 af[MT];  // af[mt][ks]: A fragment of k-step ks
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = *(const f32x4 *)(wc + (size_t)tap * (MT * 256) + mt * 256);
+                for (int mt = 0; mt < MT; ++mt) af[mt] = *(const f32x4 *)(wc + (size_t)tap * wstride + mt * 256);
                 const int toff = (ky * LW + kx) * CP;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -124,11 +130,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int seg = wave * NT + nt;
         const int r = seg / TW16, c16 = seg - r * TW16;
         const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
-        if (oy >= a.Ho || ox >= a.Wo) continue;
+        if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
             f32x4 v = acc[mt][nt];
 #pragma unroll
@@ -168,9 +174,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
     const int n = blockIdx.y;
-    const int mb = blockIdx.z;
+    const int mtile0 = blockIdx.z * MT;                 // first cout tile of this workgroup
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy0 = a.oy_base + ty * TH, ox0 = tx * TW;
     const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
     const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
     const int taps = a.KH * a.KW;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
 
     f32x4 acc[MT][NT];
     {
-        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 b = *(const f32x4 *)(bp + mt * 16);
@@ -222,7 +229,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
             }
         }
     };
-    const float *wq = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;   // walks [cb][tap] contiguously
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * taps * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
     const long wsteps = (long)a.ncb * taps;
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
             {   // next tap's weight fragments, always loaded (the last step re-reads its own block: no branch)
                 const long wn = wstep < wsteps ? wstep : wsteps - 1;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * (MT * 256) + mt * 256);
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
             }
             const float *bbase = cur + (ky * LW + kx) * CP;
             if (++kx == a.KW) { kx = 0; ++ky; }
@@ -293,11 +301,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
         const int seg = wave * NT + nt;
         const int r = seg / TW16, c16 = seg - r * TW16;
         const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
-        if (oy >= a.Ho || ox >= a.Wo) continue;
+        if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
             f32x4 v = acc[mt][nt];
 #pragma unroll
@@ -336,9 +344,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const int n = blockIdx.y;
-    const int mb = blockIdx.z;
+    const int mtile0 = blockIdx.z * MT;
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
+    const int oy0 = a.oy_base + ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
     const int LH = 3 * a.S + a.KH, LW = 15 * a.S + a.KW;
     const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
     const int taps = a.KH * a.KW;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
 
     f32x4 acc[MT][NT];
     {
-        const float *bp = a.bp + (size_t)mb * MT * 16 + 4 * (lane >> 4);
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 b = *(const f32x4 *)(bp + mt * 16);
@@ -389,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
             }
         }
     };
-    const float *wq = a.wp + (size_t)mb * a.ncb * taps * (MT * 256) + lane * 4;   // walks [cb][tap] contiguously
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * taps * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
     const long wsteps = (long)a.ncb * taps;
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
             {   // next tap's weight fragments, always loaded (the last step re-reads its own block: no branch)
                 const long wn = wstep < wsteps ? wstep : wsteps - 1;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * (MT * 256) + mt * 256);
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
             }
             const float *bbase = cur + (ky * LW + kx) * CP;
             if (++kx == a.KW) { kx = 0; ++ky; }
@@ -457,11 +467,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + (lane & 15);
-        if (oy >= a.Ho || ox >= a.Wo) continue;
+        if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int co = (mb * MT + mt) * 16 + 4 * (lane >> 4);
+            const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
             f32x4 v = acc[mt][nt];
 #pragma unroll
@@ -500,33 +510,59 @@ void choose_mt(int Cout, int &MT, int &MB) {
     MT = best_mt; MB = best_mb;
 }
 
+// Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
+struct Knob { const char *name; long value; bool set; };
+Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
+                  {"BIGPX", 131072, false}, {"V1", 0, false}, {"V2", 0, false}};
+inline long knob(const char *name) {
+    for (Knob &k : g_knobs)
+        if (!strcmp(k.name, name)) {
+            if (!k.set) {
+                char env[64];
+                snprintf(env, sizeof env, "PMCTF_CONV_%s", name);
+                const char *v = getenv(env);
+                if (v) k.value = atol(v);
+                k.set = true;
+            }
+            return k.value;
+        }
+    return 0;
+}
+
+// wave-private variant usable? (stride-1-ish patch of one wave must fit 7 staging slots and 80 KB for the workgroup)
+inline bool wave_eligible(const ConvArgs &a) {
+    const bool use_wave = knob("WAVE") != 0;
+    const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
+    const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+    const int wslots = (PH * PW * 4 + 63) / 64;
+    return use_wave && (a.Cin % CB) == 0 && wsmem <= 80 * 1024 && wslots <= 7;
+}
+
+// One launch over output rows [r0, r1) with MT cout tiles per workgroup (gz = cout-tile groups in grid.z).
 template <int MT, int NT, int TW16>
-int launch(const ConvArgs &a, int MB, hipStream_t st) {
+int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     constexpr int TW = TW16 * 16;
     constexpr int TH = NT * WAVES / TW16;
     ConvArgs b = a;
+    b.oy_base = r0;
+    b.oy_end = r1;
     b.tiles_x = (a.Wo + TW - 1) / TW;
-    b.tiles_y = (a.Ho + TH - 1) / TH;
+    b.tiles_y = (r1 - r0 + TH - 1) / TH;
     const int LH = (TH - 1) * a.S + a.KH, LW = (TW - 1) * a.S + a.KW;
     const size_t smem = (size_t)LH * LW * CP * sizeof(float);
     if (smem > 160 * 1024) return PMCTF_EINVAL;
+    dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
     if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
-        static const char *wv = getenv("PMCTF_CONV_WAVE");
-        const bool use_wave = wv ? atoi(wv) != 0 : true;
-        const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
-        const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
-        const int wslots = (PH * PW * 4 + 63) / 64;
-        if (use_wave && MT >= 4 && (a.Cin % CB) == 0 && wsmem <= 80 * 1024 && wslots <= 7) {
-            dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
+        if (MT >= 4 && wave_eligible(a)) {
+            const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
+            const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
             PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
             return pm_launch_status();
         }
     }
     {   // pipelined variant: double-buffered patch (2*smem <= 80 KB so two workgroups fit a CU), <= 9 slots/thread
-        static const bool v1_only = getenv("PMCTF_CONV_V1") != nullptr;
+        const bool v1_only = knob("V1") != 0, v2_only = knob("V2") != 0;
         const int slots = (LH * LW * 4 + 255) / 256;
-        dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
-        static const bool v2_only = getenv("PMCTF_CONV_V2") != nullptr;
         // measured (tools/bench_conv.py): the pipelined variant wins for the wide-cout tiles (MT>=7) and for 1x1
         // filters; the single-buffer variant keeps 3 waves/SIMD for MT<=4 and wins on 3x3/7x7 there.
         const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1);
@@ -541,32 +577,61 @@ int launch(const ConvArgs &a, int MB, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)conv_mfma_kernel<MT, NT, TW16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    dim3 grid(b.tiles_x * b.tiles_y, a.N, MB);
     PM_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
     return pm_launch_status();
 }
 
-template <int MT>
-int dispatch_tile(const ConvArgs &a, int MB, hipStream_t st) {
-    // big tile 8x32 (NT=4) when the image is large and stride 1; 8x16 (NT=2) for stride 2 / mid sizes;
-    // 4x16 (NT=1) for small planes so that more than a handful of workgroups exist.
+// MTP = cout tiles per packed M-block (fixed by the weight layout); chooses the tile shape and how the launch is cut.
+template <int MTP>
+int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
+    a.mtp = MTP;
     const long px = (long)a.Ho * a.Wo * a.N;
-    static const char *force_nt = getenv("PMCTF_CONV_NT");
-    if (force_nt) {
-        const int f = atoi(force_nt);
-        if (f == 4 && MT < 8 && a.S == 1) return launch<MT, 4, 2>(a, MB, st);
-        if (f == 2) return launch<MT, 2, 1>(a, MB, st);
-        if (f == 1) return launch<MT, 1, 1>(a, MB, st);
+    const long force_nt = knob("NT");
+    if (force_nt == 4 && MTP < 8 && a.S == 1) return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);
+    if (force_nt == 2) return launch<MTP, 2, 1>(a, MB, st, 0, a.Ho);
+    if (force_nt == 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+    // (1) small planes: too few 16-pixel segments to occupy 1024 SIMDs with whole M-blocks -> one cout tile per
+    //     workgroup, MTP x more (and MTP x shorter) workgroups.  Same sums, same order.
+    const long msplit_px = knob("MSPLIT_PX");
+    if (MTP >= 2 && px <= msplit_px) return launch<1, 1, 1>(a, MTP * MB, st, 0, a.Ho);
+    // (2) large planes, stride 1: 8x32 tiles.  The wave-private kernel holds 2 workgroups per CU = 512 slots; rows
+    //     that fill whole rounds of 512 go to it, the remaining rows (a partial round) are cut 4x finer (4x16 tiles)
+    //     so the tail of the launch costs a quarter of a round instead of a full one.
+    const bool split = knob("SPLIT") != 0;
+    const long big_px = split ? knob("BIGPX") : 400000;
+    if (MTP < 8 && a.S == 1 && a.KH <= 7 && px >= big_px) {
+        if (split && MTP >= 7 && wave_eligible(a)) {
+            // a CU works through its workgroups two at a time: the launch ends when the CU with the most workgroups
+            // does, so only cut when the last partial round would idle more than ~3 % of the machine
+            const long per_band = (long)a.N * ((a.Wo + 31) / 32) * MB, bands = (a.Ho + 7) / 8, slots = 512;
+            const long total = bands * per_band, rounds = total / slots;
+            const long padded = (total + 255) / 256 * 256;
+            const long bands_a = rounds * slots / per_band;
+            if (rounds >= 1 && bands_a < bands && (padded - total) * 100 > 3 * total) {
+                const int rows_a = (int)bands_a * 8;
+                const int rc = launch<MTP, 4, 2>(a, MB, st, 0, rows_a);
+                if (rc != PMCTF_OK) return rc;
+                return launch<MTP, 1, 1>(a, MB, st, rows_a, a.Ho);
+            }
+            if (rounds < 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+        }
+        if (px >= 400000L || (MTP >= 4 && wave_eligible(a))) return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);
     }
-    // measured on MI355X (tools/bench_conv.py): 8x32 tiles only pay when there are >> 256 of them; the wide-cout
-    // kernels (MT>=7) prefer 4x16 tiles on everything smaller (more workgroups -> less tail quantisation).
-    if (MT < 8 && a.S == 1 && px >= 400000L && a.KH <= 7) return launch<MT, 4, 2>(a, MB, st);
-    if (MT >= 7) return launch<MT, 1, 1>(a, MB, st);
-    if (px >= 64L * 64 * 4) return launch<MT, 2, 1>(a, MB, st);
-    return launch<MT, 1, 1>(a, MB, st);
+    // measured on MI355X (tools/bench_conv.py): the wide-cout kernels (MT>=7) prefer 4x16 tiles on everything
+    // smaller (more workgroups -> less tail quantisation).
+    if (MTP >= 7) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+    if (px >= 64L * 64 * 4) return launch<MTP, 2, 1>(a, MB, st, 0, a.Ho);
+    return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
 }
 
 }  // namespace
+
+extern "C" int pmctf_conv2d_set_option(const char *name, long value) {
+    if (!name) return PMCTF_EINVAL;
+    for (Knob &k : g_knobs)
+        if (!strcmp(k.name, name)) { k.value = value; k.set = true; return PMCTF_OK; }
+    return PMCTF_EINVAL;
+}
 
 extern "C" int64_t pmctf_conv2d_packed_bias_size(int Cout) {
     int MT, MB;
@@ -619,6 +684,7 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     a.ncb = (Cin + CB - 1) / CB;
     a.act = act; a.slope = slope;
     a.tiles_x = a.tiles_y = 0;
+    a.mtp = 1; a.oy_base = 0; a.oy_end = Ho;
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;

@@ -15,7 +15,7 @@ from . import lib as _lib
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 # Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
-# dominant kernel).  CONV_PROBE = {"match": fn(conv, x) -> bool, "events": [(start, end, flops)]}
+# dominant kernel).  CONV_PROBE = {"match": fn(conv, x, stride) -> bool, "events": [(start, end, flops)]}
 CONV_PROBE = None
 
 
@@ -84,7 +84,7 @@ class Conv2d:
             assert r is None or tuple(r.shape) == shp
         L = _lib.hip()
         fn = L.pmctf_conv2d_smallcin_f32 if self.small else L.pmctf_conv2d_nhwc_f32
-        probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](self, x)) else None
+        probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](self, x, self.stride)) else None
         if probe is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -266,9 +266,16 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
     assert H % 2 == 0 and W % 2 == 0 and Cin == conv.Cin
     py, px = cls >> 1, cls & 1
     y = torch.empty((N, H // 2, W // 2, conv.Cout), dtype=torch.float32, device=x.device)
+    probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](conv, x, 2)) else None
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H, W,
                                                      Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2, int(act),
                                                      float(slope), _stream()), "conv2d_geom")
+    if probe is not None:
+        e1.record()
+        probe["events"].append((e0, e1, 2.0 * y.numel() * Cin * 9))
     return y
 
 

@@ -130,3 +130,37 @@ def test_resample_bitexact(cuda):
     assert_same(ops.avgpool2(xt).cpu().numpy(), clib.avgpool2(x), "avgpool2")
     assert_same(ops.bilinear_up2(xt, 2.0).cpu().numpy(), clib.bilinear_up2(x) * np.float32(2), "up2")
     assert_same(ops.bilinear_down2(xt, 2.0).cpu().numpy(), clib.bilinear_down2(x) / np.float32(2), "down2")
+
+
+@pytest.mark.parametrize("shape", [(1, 112, 44, 72, 112, 3, 1), (2, 64, 70, 100, 64, 3, 1), (1, 112, 264, 520, 112, 3, 1),
+                                   (1, 32, 48, 80, 64, 7, 1), (1, 64, 64, 96, 128, 3, 2)])
+def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
+    """Every way of cutting a convolution into workgroups (cout-tile split, row split, tile size, kernel variant)
+    gives the same bits: pmctf_conv2d_set_option only moves work around."""
+    from pmctf_oracle import clib
+    from pMCTF.hip import lib, ops
+    N, Cin, H, W, Cout, K, S = shape
+    r = _rng(77 + Cin + H)
+    x = r.standard_normal((N, Cin, H, W), dtype=np.float32)
+    w = (r.standard_normal((Cout, Cin, K, K), dtype=np.float32) * 0.05).astype(np.float32)
+    b = r.standard_normal(Cout, dtype=np.float32)
+    ref = clib.conv2d(x, w, b, S, (K // 2, K // 2))
+    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2))
+    xd = nhwc(x)
+    L = lib.hip()
+    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0}
+    settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
+                {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
+                {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
+                {"V2": 1, "MSPLIT_PX": 1 << 40}]
+    try:
+        for st in settings:
+            for k, v in {**defaults, **st}.items():
+                assert L.pmctf_conv2d_set_option(k.encode(), v) == 0
+            y = conv(xd)
+            torch.cuda.synchronize()
+            assert_same(nchw(y), ref, f"conv {shape} with options {st}")
+    finally:
+        for k, v in defaults.items():
+            L.pmctf_conv2d_set_option(k.encode(), v)
+    assert L.pmctf_conv2d_set_option(b"NO_SUCH_KNOB", 1) != 0

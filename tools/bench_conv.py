@@ -15,6 +15,12 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("ctx112 L1 luma 288x480", 1, 288, 480, 112, 112, 3, 1, 1),
     ("ctx112 L2 luma 144x240", 1, 144, 240, 112, 112, 3, 1, 1),
     ("ctx112 L3 luma 72x120", 1, 72, 120, 112, 112, 3, 1, 1),
+    ("ctx112 L1 chroma 2x144x240", 2, 144, 240, 112, 112, 3, 1, 1),
+    ("ctx112 L2 chroma 2x72x120", 2, 72, 120, 112, 112, 3, 1, 1),
+    ("ctx112 L3 chroma 2x36x60", 2, 36, 60, 112, 112, 3, 1, 1),
+    ("post64 chroma 2x576x960", 2, 576, 960, 64, 64, 3, 1, 1),
+    ("lstm 32->32 2x288x480", 2, 288, 480, 32, 32, 3, 1, 1),
+    ("pu 16->16 960x576", 1, 960, 576, 16, 16, 3, 1, 1),
     ("post64 luma 1152x1920", 1, 1152, 1920, 64, 64, 3, 1, 1),
     ("spynet 32->64 7x7 1152x1920", 1, 1152, 1920, 32, 64, 7, 1, 3),
     ("spynet 8->32 7x7 1152x1920", 1, 1152, 1920, 8, 32, 7, 1, 3),
@@ -29,6 +35,11 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     only = sys.argv[2] if len(sys.argv) > 2 else None
     torch.manual_seed(0)
+    from pMCTF.hip import lib
+    for kv in sys.argv[3:]:                     # NAME=VALUE launch-shape knobs (pmctf_conv2d_set_option)
+        k, v = kv.split("=")
+        assert lib.hip().pmctf_conv2d_set_option(k.encode(), int(v)) == 0
+    print("options:", sys.argv[3:])
     for name, N, H, W, Cin, Cout, K, S, P in SHAPES:
         if only and only not in name:
             continue

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-signature census of the convolutions of one 1080p GOP-16 encode: launches, time, TFLOP/s (HIP events)."""
+import collections, os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
+import torch
+import pmctf_gop, pmctf_synth
+from pMCTF.models.video.pMCTF_L import pMCTF
+from pMCTF.hip import ops
+net = pMCTF(num_me_stages=4).eval()
+net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), strict=True)
+net = net.cuda(); net.update(force=True)
+W, H, G = 1920, 1080, 16
+frames = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420(W, H, G)]
+tmp = tempfile.mkdtemp()
+sigs = []
+def match(conv, x, stride):
+    sigs.append((tuple(x.shape), conv.Cout, conv.KH, stride))
+    return True
+with torch.no_grad():
+    pmctf_gop.encode_gop(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
+    probe = {"match": match, "events": []}
+    ops.CONV_PROBE = probe
+    pmctf_gop.encode_gop(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
+    ops.CONV_PROBE = None
+agg = collections.OrderedDict()
+for s, (e0, e1, fl) in zip(sigs, probe["events"]):
+    a = agg.setdefault(s, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+tot = sum(a[1] for a in agg.values())
+print(f"total conv ms {tot:.1f}  total TFLOP {sum(a[2] for a in agg.values())/1e12:.1f}")
+for s, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    (N, h, w, ci), co, k, st = s
+    print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{st}  n={a[0]:5d} {a[1]:8.1f} ms ({a[1]/tot*100:4.1f}%) {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
