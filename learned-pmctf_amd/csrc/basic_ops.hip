@@ -104,6 +104,74 @@ __global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const floa
     }
 }
 
+
+// 3x3, stride 1, pad 1, Cin <= 3, many couts (1->64/112/128, 2->112): a WAVE owns a strip of 16 consecutive output
+// pixels of one row and up to 64 couts (lane = cout).  All lanes of the wave read the same input taps, so the 3x18xCIN
+// input window is fetched with wave-uniform (scalar) loads once per strip and every output costs 9*CIN FMAs plus one
+// coalesced store — no per-output index arithmetic.  Same sum order: acc = bias; for ky: for kx: for ci: fmaf.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float *__restrict__ x,
+                                                                     const float *__restrict__ w,
+                                                                     const float *__restrict__ bias, const float *res1,
+                                                                     const float *res2, float *y, int N, int H, int W,
+                                                                     int Cout, int act, float slope, int cgroups,
+                                                                     int strips_per_row, long total_strips) {
+    constexpr int P = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = wave % cgroups;                       // cgroups in {1,2,4}
+    const int spb = 4 / cgroups;                         // strips per block and pass
+    const int co = cg * 64 + lane;
+    const bool active = co < Cout;
+    const int cw = active ? co : 0;
+    float wr[9 * CIN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(cw * CIN + ci) * 9 + t];
+    const float b = bias ? bias[cw] : 0.0f;
+    for (long strip = (long)blockIdx.x * spb + wave / cgroups; strip < total_strips; strip += (long)gridDim.x * spb) {
+        const int sx = (int)(strip % strips_per_row) * P;
+        const long r = strip / strips_per_row;
+        const int oy = (int)(r % H);
+        const int n = (int)(r / H);
+        float in[3][P + 2][CIN];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            const bool rowok = iy >= 0 && iy < H;
+            const float *xr = x + ((size_t)n * H + (rowok ? iy : 0)) * W * CIN;
+#pragma unroll
+            for (int j = 0; j < P + 2; ++j) {
+                const int ix = sx + j - 1;
+                const bool ok = rowok && ix >= 0 && ix < W;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) in[ky][j][ci] = ok ? xr[(size_t)ix * CIN + ci] : 0.0f;
+            }
+        }
+        if (!active) continue;
+        const size_t obase = (((size_t)n * H + oy) * W + sx) * Cout + co;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            if (sx + j < W) {
+                float acc = b;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci)
+                            acc = __builtin_fmaf(in[ky][j + kx][ci], wr[(ky * 3 + kx) * CIN + ci], acc);
+                float v = pm::apply_act(acc, act, slope);
+                const size_t o = obase + (size_t)j * Cout;
+                if (res1) v = v + res1[o];
+                if (res2) v = v + res2[o];
+                y[o] = v;
+            }
+        }
+    }
+}
+
 // depthwise KxK, stride 1, pad K/2; NHWC, channel fastest
 __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                               float *y, int N, int H, int W, int C, int K) {
@@ -248,6 +316,24 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         return PMCTF_EINVAL;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
+    if (KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 48 && Cout <= 256) {
+        const int cg0 = (Cout + 63) / 64, cgroups = cg0 == 3 ? 4 : cg0;
+        const int strips_per_row = (W + 15) / 16;
+        const long total_strips = (long)N * H * strips_per_row;
+        const int spb = 4 / cgroups;
+        long nb = (total_strips + spb - 1) / spb;
+        if (nb > 8192) nb = 8192;
+        dim3 grid((unsigned)nb), block(256);
+        hipStream_t st = (hipStream_t)stream;
+#define PM_STRIP(C_)                                                                                                 \
+    PM_LAUNCH((conv3x3_smallcin_strip_kernel<C_>), grid, block, 0, st, x, w, bias, res1, res2, y, N, H, W, Cout, act,  \
+              slope, cgroups, strips_per_row, total_strips);                                                         \
+    return launch_ok();
+        if (Cin == 1) { PM_STRIP(1) }
+        if (Cin == 2) { PM_STRIP(2) }
+        if (Cin == 3) { PM_STRIP(3) }
+#undef PM_STRIP
+    }
     if (KH == KW && Cout <= 256 && (long)N * Ho * Wo < (1L << 31)) {
         const int ppp = 256 / Cout;
         long nb = ((long)N * Ho * Wo + ppp - 1) / ppp;

@@ -47,6 +47,10 @@ CONV_CASES = [
     (2, 2, 37, 53, 112, 3, 1, 1, 0, 0.0, 0),       # small-cin 2->112
     (1, 2, 64, 96, 64, 3, 2, 1, 2, 0.01, 0),       # small-cin stride 2
     (1, 3, 30, 40, 3, 3, 1, 1, 0, 0.0, 1),         # 3->3 with residual
+    (1, 1, 45, 83, 112, 3, 1, 1, 2, 0.2, 0),       # strip kernel: 1->112, ragged width, leaky
+    (2, 1, 18, 16, 64, 3, 1, 1, 0, 0.0, 2),        # strip kernel: 1->64, one strip per row, two residual adds
+    (1, 1, 20, 36, 128, 3, 1, 1, 3, 0.0, 0),       # strip kernel: 1->128 + tanh
+    (1, 3, 17, 40, 192, 3, 1, 1, 0, 0.0, 1),       # strip kernel: 3->192 (3 cout groups -> 4 waves, one idle)
 ]
 
 
