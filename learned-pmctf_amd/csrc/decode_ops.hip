@@ -85,11 +85,13 @@ __device__ __forceinline__ float dense128(const float *__restrict__ wl, const fl
     return acc;
 }
 
-__global__ __launch_bounds__(256) void ll_ar_decode_kernel(LLArgs a) {
-    __shared__ float act[2][TB * NF];     // per plane: gathered causal activations of the current layer
-    __shared__ float vec[2][NF];          // per plane: a 128-vector passed between 1x1 layers
-    __shared__ float prm[2][2];           // per plane: (scale, mean)
-    __shared__ float newval[2];
+constexpr int LL_MAX_PLANES = 4;          // one 128-thread group per plane of the stream (Y: 1, UV: 2, RGB: 3)
+
+__global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArgs a) {
+    __shared__ float act[LL_MAX_PLANES][TB * NF];     // per plane: gathered causal activations of the current layer
+    __shared__ float vec[LL_MAX_PLANES][NF];          // per plane: a 128-vector passed between 1x1 layers
+    __shared__ float prm[LL_MAX_PLANES][2];           // per plane: (scale, mean)
+    __shared__ float newval[LL_MAX_PLANES];
     const int tid = threadIdx.x;
     const int plane = tid >> 7;
     const int co = tid & (NF - 1);
@@ -367,7 +369,7 @@ extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *str
                                       int cdf_cols, float log_scale_min, float log_scale_step, float *ll_out,
                                       float *scratch_zeroed, int N, int H, int W, uint64_t *state_out, void *stream) {
     if (!w_packed || !stream_words || !cdf || !sizes || !offsets || !ll_out || !scratch_zeroed || !state_out || N < 1 ||
-        N > 2 || H < 1 || W < 1 || n_words < 0 || cdf_cols < 3)
+        N > LL_MAX_PLANES || H < 1 || W < 1 || n_words < 0 || cdf_cols < 3)
         return PMCTF_EINVAL;
     LLArgs a;
     a.w = w_packed; a.stream = stream_words; a.n_words = n_words; a.x0 = x0; a.pos0 = pos0;
@@ -375,7 +377,7 @@ extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *str
     a.lmin = log_scale_min; a.lstep = log_scale_step;
     a.ll_out = ll_out; a.bufs = scratch_zeroed; a.N = N; a.H = H; a.W = W;
     a.state_out = (unsigned long long *)state_out;
-    PM_LAUNCH(ll_ar_decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    PM_LAUNCH(ll_ar_decode_kernel, dim3(1), dim3(128 * N), 0, (hipStream_t)stream, a);
     return launch_ok();
 }
 

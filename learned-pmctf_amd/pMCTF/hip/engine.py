@@ -544,15 +544,22 @@ class HipEngine:
             n += 3 * 4 * N * (H >> (lvl + 1)) * (W >> (lvl + 1))
         return n
 
+    def q_scales(self, coder, q_index, qp_scale=None):
+        """quantisation step of a coder's subbands and of its LL subband (pWave.py:383-393,468-478)"""
+        if q_index is None:
+            q_scale, q_scale_ll = self.sd[f"{coder}.QP"][-1], self.sd[f"{coder}.QP_ll"][-1]
+        else:
+            q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+            q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+            if qp_scale is not None:
+                q_scale = q_scale * qp_scale
+                q_scale_ll = q_scale_ll * qp_scale
+        return float(q_scale), float(q_scale_ll)
+
     def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False):
         """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream).  ar_order: LL symbols in the sequential coder's
         order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555)."""
-        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
-        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
-        if qp_scale is not None:
-            q_scale = q_scale * qp_scale
-            q_scale_ll = q_scale_ll * qp_scale
-        q_scale, q_scale_ll = float(q_scale), float(q_scale_ll)
+        q_scale, q_scale_ll = self.q_scales(coder, q_index, qp_scale)
         N, _, H, W = x.shape
         clip = 8192.0
         y = {}
@@ -649,24 +656,39 @@ class HipEngine:
         """device int16 CDF rows -> host range decoder -> device int16 symbols"""
         return torch.from_numpy(dec.decode(idx_dev.cpu().numpy(), table)).to(self.dev)
 
-    def ll_ar_decode(self, coder, dec, N, H, W):
+    def ll_ar_launch(self, coder, dec, N, H, W, stream=None):
+        """Enqueue the sequential LL decode (one persistent workgroup) on `stream`; returns a ticket for ll_ar_finish.
+        The LL streams of different files are independent, so callers start all of them before waiting for any."""
+        if N > 4:
+            raise NotImplementedError("the sequential LL decoder handles up to 4 planes per stream (Y / UV / RGB)")
         L = _lib.hip()
         w = self._ll_weights(coder)
         cdf, sizes, offsets = self._dev_tables("gauss")
-        words = torch.from_numpy(dec.words.copy()).to(self.dev)
         x, pos = dec.get_state()
-        ll = torch.zeros((N, 1, H, W), dtype=torch.float32, device=self.dev)
-        scratch = torch.zeros(L.pmctf_ll_ar_scratch_floats(N, H, W), dtype=torch.float32, device=self.dev)
-        state = torch.zeros(3, dtype=torch.int64, device=self.dev)
-        vp = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(L.pmctf_ll_ar_decode_f32(vp(w), vp(words), words.numel(), C.c_uint64(x), pos, vp(cdf), vp(sizes),
-                                            vp(offsets), cdf.shape[1], float(self.lmin), float(self.lstep), vp(ll),
-                                            vp(scratch), N, H, W, vp(state), ops._stream()), "ll_ar_decode")
-        st = state.cpu().numpy()
+        st = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(st):
+            words = torch.from_numpy(dec.words.copy()).to(self.dev)
+            ll = torch.zeros((N, 1, H, W), dtype=torch.float32, device=self.dev)
+            scratch = torch.zeros(L.pmctf_ll_ar_scratch_floats(N, H, W), dtype=torch.float32, device=self.dev)
+            state = torch.zeros(3, dtype=torch.int64, device=self.dev)
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            _lib.check(L.pmctf_ll_ar_decode_f32(vp(w), vp(words), words.numel(), C.c_uint64(x), pos, vp(cdf), vp(sizes),
+                                                vp(offsets), cdf.shape[1], float(self.lmin), float(self.lstep), vp(ll),
+                                                vp(scratch), N, H, W, vp(state), C.c_void_p(st.cuda_stream)),
+                       "ll_ar_decode")
+        return {"dec": dec, "ll": ll, "state": state, "stream": st, "keep": (words, scratch)}
+
+    def ll_ar_finish(self, t):
+        t["stream"].synchronize()
+        st = t["state"].cpu().numpy()
         if st[2] != 0:
             raise ValueError("LL decode ran past the end of the bitstream")
-        dec.set_state(int(np.uint64(st[0])), int(st[1]))
-        return ll
+        t["dec"].set_state(int(np.uint64(st[0])), int(st[1]))
+        t["ll"].record_stream(torch.cuda.current_stream(self.dev))
+        return t["ll"]
+
+    def ll_ar_decode(self, coder, dec, N, H, W):
+        return self.ll_ar_finish(self.ll_ar_launch(coder, dec, N, H, W))
 
     def fusion_decompress(self, p, ctx, prev, dec, N, H, W):
         """ContextFusionFourStep.decompress (context_fusion_4step.py:196-249)"""
@@ -700,22 +722,36 @@ class HipEngine:
             ops.fourstep_dequant(sym, params, so_far, step)
         return so_far
 
-    def pwave_decompress(self, coder, data, padding, q_index, qp_scale=None):
-        """pWave.decompress (pWave.py:467-529) from the bytes of one bitstream file -> x_hat plane (N,1,Hp,Wp)"""
+    def pwave_decompress_begin(self, coder, data, padding, q_index, qp_scale=None, stream=None):
+        """Parse one bitstream file and start its sequential LL decode; finish with pwave_decompress_end."""
         import struct
-        q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
-        q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
-        if qp_scale is not None:
-            q_scale = q_scale * qp_scale
-            q_scale_ll = q_scale_ll * qp_scale
-        q_scale, q_scale_ll = float(q_scale), float(q_scale_ll)
+        q_scale, q_scale_ll = self.q_scales(coder, q_index, qp_scale)
         height, width, N = struct.unpack(">III", data[:12])
         (n,) = struct.unpack(">I", data[12:16])
         dec = HostDecoder(self.tables, data[16:16 + n])
         new_h = (height + padding - 1) // padding * padding
         new_w = (width + padding - 1) // padding * padding
         sh, sw = new_h >> self.L, new_w >> self.L
-        ll_rec = self.ll_ar_decode(coder, dec, N, sh, sw)
+        ticket = self.ll_ar_launch(coder, dec, N, sh, sw, stream)
+        return {"coder": coder, "dec": dec, "ticket": ticket, "q": (q_scale, q_scale_ll), "N": N,
+                "shape": (new_h, new_w, sh, sw)}
+
+    def pwave_decompress(self, coder, data, padding, q_index, qp_scale=None):
+        """pWave.decompress (pWave.py:467-529) from the bytes of one bitstream file -> x_hat plane (N,1,Hp,Wp)"""
+        return self.pwave_decompress_end(self.pwave_decompress_begin(coder, data, padding, q_index, qp_scale))
+
+    def pwave_decompress_many(self, jobs):
+        """jobs: [(coder, data, padding, q_index, qp_scale)].  All LL decodes run concurrently on side streams."""
+        while len(self.side_streams) < len(jobs):
+            self.side_streams.append(torch.cuda.Stream(device=self.dev))
+        begun = [self.pwave_decompress_begin(*j, stream=self.side_streams[i]) for i, j in enumerate(jobs)]
+        return [self.pwave_decompress_end(b) for b in begun]
+
+    def pwave_decompress_end(self, job):
+        coder, dec, N = job["coder"], job["dec"], job["N"]
+        q_scale, q_scale_ll = job["q"]
+        new_h, new_w, sh, sw = job["shape"]
+        ll_rec = self.ll_ar_finish(job["ticket"])
         hat = {lvl: {} for lvl in range(self.L)}
         hat[self.L - 1]["ll"] = ll_rec
         lstm_state = self.ctx_init(N, sh, sw)

@@ -37,6 +37,7 @@ class pWave(nn.Module):
         self.QP = nn.Parameter(torch.ones((2, 1, 1, 1), dtype=torch.float) * 1 / 16)
         self.QP_ll = nn.Parameter(torch.ones((2, 1, 1, 1), dtype=torch.float) * 1 / 16)
         self.apply(self._init_weights)
+        self._engine = None
 
     @staticmethod
     def _init_weights(m):
@@ -51,3 +52,53 @@ class pWave(nn.Module):
 
     def update(self, force=False):
         self.em.update(force)
+        self._engine = None
+
+    def get_curr_q(self, q_scale, q_index):
+        """pWave.py:217-226"""
+        from pMCTF.hip.engine import get_curr_q
+        return get_curr_q(q_scale.detach().cpu(), q_index)
+
+    def engine(self):
+        """This coder's parameters on the GPU engine (built on first use, after update())."""
+        if getattr(self, "_engine", None) is None:
+            from pMCTF.hip.engine import HipEngine
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("pWave (MI355X build) codes on the GPU only: move the model to 'cuda'; "
+                                   "there is no CPU path")
+            ge = self.em.gaussian_encoder
+            if ge.get_cdf_info()[0] is None:
+                raise RuntimeError("call update(force=True) before coding")
+            g = {"cdf_info": ge.get_cdf_info(), "log_scale_min": ge.log_scale_min, "log_scale_step": ge.log_scale_step}
+            sd = {"coder." + k: v for k, v in self.state_dict().items()}
+            self._engine = HipEngine(sd, 0, dev, g, [], decomp_levels=self.decomp_levels)
+        return self._engine
+
+    @torch.no_grad()
+    def compress(self, x, sideinfo=None, file_name=None, q_index=None, skip_decoding=False, qp_scale=None):
+        """pWave.py:380-464: code one image (Y, UV or RGB planes; sizes already padded) into `file_name`, return x_hat.
+        With skip_decoding=False the LL subband is written in the sequential decoder's order."""
+        from pMCTF.utils.stream_helper import image_header
+        _, num_channels, height, width = sideinfo
+        x_in = torch.cat([x[:, c:c + 1] for c in range(3)], dim=0) if num_channels == 3 else x
+        eng = self.engine()
+        qs = None if qp_scale is None else float(qp_scale)
+        x_hat, stream = eng.pwave_compress("coder", x_in.contiguous().float(), q_index, qs, ar_order=not skip_decoding)
+        hdr = lambda n: image_header(height, width, num_channels, n)
+        eng.coder.submit(stream, eng.tables, hdr, file_name).result()
+        if num_channels == 3:
+            x_hat = torch.cat([x_hat[c:c + 1] for c in range(3)], dim=1)
+        return x_hat
+
+    @torch.no_grad()
+    def decompress(self, file_name, padding=64, q_index=None, qp_scale=None):
+        """pWave.py:466-529"""
+        eng = self.engine()
+        with open(file_name, "rb") as f:
+            data = f.read()
+        qs = None if qp_scale is None else float(qp_scale)
+        x_hat = eng.pwave_decompress("coder", data, padding, q_index, qs)
+        if x_hat.shape[0] == 3:
+            x_hat = torch.cat([x_hat[c:c + 1] for c in range(3)], dim=1)
+        return {"x_hat": x_hat}

@@ -137,18 +137,31 @@ class pMCTF(nn.Module):
     @torch.no_grad()
     def decompress_one_stage(self, file_name, code_lt, ischroma, psize=128, q_index=0, stage_idx=0):
         """pMCTF_L.py:422-439"""
+        return self._decompress_files([(file_name, ischroma)], code_lt, psize, q_index, stage_idx)[0]
+
+    def _decompress_files(self, files, code_lt, psize, q_index, stage_idx):
+        """H (and L) files of the given (file_name, ischroma) entries; their sequential LL parts decode concurrently"""
         from pMCTF.hip.engine import get_curr_q
         eng = self.engine()
         qp_scale = get_curr_q(eng.sd[f"hp_q_scale.{stage_idx}"], q_index) if self.quant_stage else None
-        pad = psize // 2 if ischroma else psize
-        with open(file_name, "rb") as f:
-            H_t = eng.pwave_decompress("hp_coder", f.read(), pad, q_index, qp_scale)
-        L_t = None
-        if code_lt:
-            file_name_l = file_name.replace(osp.basename(file_name), "0_C_main.bin" if ischroma else "0_main.bin")
-            with open(file_name_l, "rb") as f:
-                L_t = {"x_hat": eng.pwave_decompress("lp_coder", f.read(), pad, q_index)}
-        return {"L_t": L_t, "H_t": {"x_hat": H_t}}
+        jobs = []
+        for file_name, ischroma in files:
+            pad = psize // 2 if ischroma else psize
+            with open(file_name, "rb") as f:
+                jobs.append(("hp_coder", f.read(), pad, q_index, qp_scale))
+            if code_lt:
+                file_name_l = file_name.replace(osp.basename(file_name), "0_C_main.bin" if ischroma else "0_main.bin")
+                with open(file_name_l, "rb") as f:
+                    jobs.append(("lp_coder", f.read(), pad, q_index, None))
+        planes = eng.pwave_decompress_many(jobs)
+        out, i = [], 0
+        for _ in files:
+            H_t = planes[i]; i += 1
+            L_t = None
+            if code_lt:
+                L_t = {"x_hat": planes[i]}; i += 1
+            out.append({"L_t": L_t, "H_t": {"x_hat": H_t}})
+        return out
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("estimate-mode / training forward is outside the encode hot path of this build")
@@ -239,10 +252,8 @@ class pMCTF(nn.Module):
                                          q_index=q_index)
             mv_hat = decoded["mv_hat"]
             mv_feature = decoded["mv_feature"].permute(0, 2, 3, 1)
-            out_dec = self.decompress_one_stage(output_path, code_lt, ischroma=False, psize=psize, q_index=q_index,
-                                                stage_idx=stage_idx)
-            out_dec_c = self.decompress_one_stage(file_name_c, code_lt, ischroma=True, psize=psize, q_index=q_index,
-                                                  stage_idx=stage_idx)
+            out_dec, out_dec_c = self._decompress_files([(output_path, False), (file_name_c, True)], code_lt, psize,
+                                                        q_index, stage_idx)
             torch.cuda.synchronize()
             decoding_time = time.time() - t0
             luma = dict(luma, H_t_hat=out_dec["H_t"]["x_hat"], L_t_hat=out_dec["L_t"]["x_hat"] if code_lt else None)

@@ -143,3 +143,56 @@ def test_decoder_round_trip_and_oracle(setup):
     g = golden()   # the real reference with its decoder in the loop: same sizes, reconstruction within fp noise
     assert np.abs(r["H_t"].cpu().numpy() - g["dec.H_t"]).max() < 2e-3
     assert r["bit_ME"] == g["dec.bits"][2]
+
+
+def test_still_image_coder_256(setup):
+    """BASELINE configs[0]: the pWave++ still-image coder on one 256x256 frame through pWave.compress / decompress
+    (Y plane, then three planes as an RGB image), decoder-order stream, against the oracle's coder and decoder."""
+    import os
+    net, orc = setup
+    img = frames(256, 256, 1)[0][0]
+    coder = net.lp_coder
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "img.bin")
+        x_hat = coder.compress(img.cuda(), [1, 1, 256, 256], fn, q_index=3, skip_decoding=False)
+        data = open(fn, "rb").read()
+        dec = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
+        ox, odata, _ = orc.pwave_compress("lp_coder", img, [1, 1, 256, 256], 3, None, skip_decoding=False)
+        assert data == odata, "still-image bitstream differs from the oracle"
+        assert_same(x_hat, ox, "still image x_hat")
+        assert_same(dec, x_hat, "decoded still image vs encoder reconstruction")
+        assert_same(dec, orc.pwave_decompress("lp_coder", odata, 64, 3), "decoded still image vs oracle decoder")
+        # three planes in one stream (the RGB branch, pWave.py:394-396,459-460,524-525)
+        rgb = torch.cat([img, img.flip(2), img.flip(3)], dim=1)
+        x3 = coder.compress(rgb.cuda(), [1, 3, 256, 256], fn, q_index=7, skip_decoding=False)
+        d3 = coder.decompress(fn, padding=64, q_index=7)["x_hat"]
+        planes = torch.cat([rgb[:, c:c + 1] for c in range(3)], dim=0)
+        o3, o3data, _ = orc.pwave_compress("lp_coder", planes, [1, 3, 256, 256], 7, None, skip_decoding=False)
+        assert open(fn, "rb").read() == o3data
+        assert x3.shape == (1, 3, 256, 256) and d3.shape == (1, 3, 256, 256)
+        assert_same(d3, x3, "decoded RGB vs encoder reconstruction")
+        assert_same(torch.cat([x3[:, c:c + 1] for c in range(3)], dim=0), o3, "RGB x_hat vs oracle")
+
+
+def test_two_me_stages_cropped_frame(cuda):
+    """num_me_stages=2 parameter tree, second stage (stage_idx=1), a 176x144 picture padded to 256x256, no L coding,
+    q_index 0: files and tensors identical to the oracle."""
+    import os
+    from pmctf_oracle.model import Oracle
+    net, sd = product_model(2)
+    orc = Oracle(sd, 2, "cdef")
+    w, h = 176, 144
+    fr = frames(w, h, 2, seed=99)
+    assert fr[0][0].shape[-2:] == (256, 256)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    with tempfile.TemporaryDirectory() as td:
+        r = net.encode_one_stage(frd[0], frd[1], False, dpb, output_path=os.path.join(td, "3.bin"), pic_width=w,
+                                 pic_height=h, skip_decoding=True, stage_idx=1, q_index=0)
+        names = sorted(os.listdir(td))
+    o = orc.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=w, pic_height=h, q_index=0, stage_idx=1)
+    assert "0_main.bin" not in names and len(names) == 3
+    for k in ("H_t", "H_tc", "mv_hat"):
+        assert_same(r[k], o[k], k)
+    assert r["bit_H"] == o["bit_H"] == 8 * (len(o["files"]["H"]) + len(o["files"]["Hc"])) and r["bit_L"] is None
+    assert r["bit_ME"] == o["bit_ME"] == 8 * len(o["files"]["mv"])

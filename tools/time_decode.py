@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""1080p decode timing for one pair (skip_decoding=False): total and the sequential LL kernel alone."""
+"""1080p decode timing for one pair (skip_decoding=False)."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
@@ -12,20 +12,10 @@ net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), stri
 net = net.cuda(); net.update(force=True)
 W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
 fr = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420(W, H, 2)]
-eng = net.engine()
-orig = eng.ll_ar_decode
-acc = {"ll": 0.0, "n": 0}
-def timed(coder, dec, N, h, w):
-    torch.cuda.synchronize(); t = time.time(); r = orig(coder, dec, N, h, w); torch.cuda.synchronize()
-    acc["ll"] += time.time() - t; acc["n"] += 1
-    print(f"  ll_ar {coder} N={N} {h}x{w}: {time.time()-t:.3f}s", flush=True)
-    return r
-eng.ll_ar_decode = timed
 tmp = tempfile.mkdtemp()
 with torch.no_grad():
     for it in range(2):
-        acc["ll"] = 0
         dpb = {"mv_feature": None, "ref_mv_y": None}
         r = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=os.path.join(tmp, "1.bin"), pic_width=W, pic_height=H,
                                  skip_decoding=False, stage_idx=0, q_index=3)
-        print("decoding_time", r["decoding_time"], "LL total", acc["ll"], flush=True)
+        print("decoding_time", r["decoding_time"], flush=True)
