@@ -196,3 +196,53 @@ def test_two_me_stages_cropped_frame(cuda):
         assert_same(r[k], o[k], k)
     assert r["bit_H"] == o["bit_H"] == 8 * (len(o["files"]["H"]) + len(o["files"]["Hc"])) and r["bit_L"] is None
     assert r["bit_ME"] == o["bit_ME"] == 8 * len(o["files"]["mv"])
+
+
+@pytest.mark.parametrize("q_index", [0, 12, 20])
+def test_rate_points_match_oracle(setup, q_index):
+    """RD sweep end points (q_index 0..20): one pair per rate point, files and reconstructions identical to the oracle."""
+    import os
+    net, orc = setup
+    fr = frames(W, H, 2, seed=7)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    with tempfile.TemporaryDirectory() as td:
+        r = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                 pic_height=H, skip_decoding=True, stage_idx=0, q_index=q_index)
+    o = orc.encode_one_stage(fr[0], fr[1], True, dpb, pic_width=W, pic_height=H, q_index=q_index)
+    for k in o["files"]:
+        assert r["files"][k] == o["files"][k], f"q_index {q_index}: file {k} differs"
+    for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+        assert_same(r[k], o[k], f"q_index {q_index}: {k}")
+
+
+def test_full_size_1080p_properties(cuda):
+    """At the benchmark's full size (1920x1080, 4 ME stages) the oracle is too slow, so check what must hold at any
+    size: (1) the decoder reproduces the encoder's reconstruction bit for bit from the written files, (2) the files
+    account for the reported bits, (3) the lifting is inverted by inverse_MCTF up to rounding, (4) coding is
+    deterministic (same bytes twice)."""
+    import os
+    net, _ = product_model(4)
+    w, h = 1920, 1080
+    fr = frames(w, h, 2, device="cuda", seed=5)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "1.bin")
+        e = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=out, pic_width=w, pic_height=h,
+                                 skip_decoding=True, stage_idx=0, q_index=3)
+        first = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+        e2 = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=out, pic_width=w, pic_height=h,
+                                  skip_decoding=True, stage_idx=0, q_index=3)
+        again = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+        assert first == again and len(first) == 5
+        assert e["bit_H"] + e["bit_L"] + e["bit_ME"] == 8 * sum(len(v) for v in first.values())
+        d = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=out, pic_width=w, pic_height=h,
+                                 skip_decoding=False, stage_idx=0, q_index=3)
+    for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+        assert_same(d[k], e[k], f"1080p decoded {k} vs encoder reconstruction")
+        assert_same(e2[k], e[k], f"1080p {k} second run")
+    assert e["H_t"].shape == (1, 1, 1152, 1920) and e["H_tc"].shape == (2, 1, 576, 960)
+    # (3) analysis -> synthesis with the coded motion field
+    L_t, H_t, _, _ = net.forward_MCTF(fr[0][0], fr[1][0], e["mv_hat"])
+    ref, cur = net.inverse_MCTF(L_t, H_t, e["mv_hat"])
+    assert (ref - fr[0][0]).abs().max().item() < 1e-3 and (cur - fr[1][0]).abs().max().item() < 1e-3
