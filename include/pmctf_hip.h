@@ -81,6 +81,20 @@ int pmctf_conv2d_smallcin_f32(const float *x, const float *w_oihw, const float *
                               int N, int H, int W, int Cin, int Cout, int KH, int KW,
                               int stride, int pad_h, int pad_w, int act, float slope, void *stream);
 
+/* PredictUpdate conv1 (pMCTF/layers/lifting_1d.py:38,44-45): 3x3, stride 1, pad 1, one input channel, Cout = 16
+ * (other Cout: PMCTF_EINVAL).  y = conv(x); if y2 != NULL also y2 = act2(conv(x)) — the block needs both conv1 and
+ * tanh(conv1).  x [N,H,W] plane, w OIHW on the device, y/y2 [N,H,W,16]. */
+int pmctf_conv3x3_cin1_dual_f32(const float *x, const float *w_oihw, const float *bias, float *y, float *y2,
+                                int N, int H, int W, int Cout, int act2, float slope, void *stream);
+
+/* KxK, stride 1, pad K/2, one or two output channels (PredictUpdate conv4 16->1 lifting_1d.py:41, PostProcess 64->1,
+ * SpyNet 16->2 7x7): vector-ALU kernel, plain OIHW weights on the device, same sum order as pmctf_conv2d_nhwc_f32.
+ * pmctf_conv2d_fewcout_supported() tells which (Cin, Cout, K) exist; others return PMCTF_EINVAL. */
+int pmctf_conv2d_fewcout_supported(int Cin, int Cout, int K);
+int pmctf_conv2d_fewcout_f32(const float *x, const float *w_oihw, const float *bias, const float *res1,
+                             const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int K,
+                             int act, float slope, void *stream);
+
 /* depthwise KxK conv, stride 1, pad K/2 (pMCTF/layers/video/layers.py:117-118); x,y [N,H,W,C], w [C,1,K,K] */
 int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y,
                             int N, int H, int W, int C, int K, void *stream);

@@ -172,6 +172,104 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
     }
 }
 
+// 3x3, stride 1, pad 1, ONE input channel, 16 couts (PredictUpdate conv1, lifting_1d.py:38): lane = pixel, the 144
+// weights are wave-uniform, a lane writes its pixel's 16 couts as 64 contiguous bytes.  Optionally also writes
+// act2(conv) to a second tensor (the PredictUpdate block needs both conv1 and tanh(conv1)).
+__global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                 const float *__restrict__ bias, float *y, float *y2,
+                                                                 int N, int H, int W, int act2, float slope) {
+    const long total = (long)N * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % W);
+        const long r = idx / W;
+        const int oy = (int)(r % H);
+        const float *plane = x + (r - oy) * W;           // start of image n
+        float in[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                in[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(long)iy * W + ix] : 0.0f;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = q * 4 + i;
+                float acc = bias ? bias[co] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(in[t], w[co * 9 + t], acc);
+                v[i] = acc;
+            }
+            *(float4 *)(y + idx * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            if (y2)
+                *(float4 *)(y2 + idx * 16 + q * 4) =
+                    make_float4(pm::apply_act(v[0], act2, slope), pm::apply_act(v[1], act2, slope),
+                                pm::apply_act(v[2], act2, slope), pm::apply_act(v[3], act2, slope));
+        }
+    }
+}
+
+// KxK, stride 1, pad K/2, Cin a multiple of 16, ONE or TWO couts (PredictUpdate conv4 16->1, PostProcess 64->1, SpyNet
+// 16->2): a matrix-core tile would be 15/16 empty, so lane = pixel on the vector ALU, weights wave-uniform, the 16
+// channels of a tap are one 64-byte run per lane.  Sum order of the spec: chunk, ky, kx, ci.
+template <int K, int CIN, int CO>
+__global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, const float *res1,
+                                                               const float *res2, float *y, int N, int H, int W, int act,
+                                                               float slope) {
+    constexpr int P = K / 2;
+    const long total = (long)N * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % W);
+        const long r = idx / W;
+        const int oy = (int)(r % H);
+        const float *img = x + (r - oy) * W * CIN;
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = bias ? bias[co] : 0.0f;
+#pragma unroll 1
+        for (int cb = 0; cb < CIN / 16; ++cb) {
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy + ky - P;
+                const bool rowok = iy >= 0 && iy < H;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int ix = ox + kx - P;
+                    float v[16];
+                    if (rowok && ix >= 0 && ix < W) {
+                        const float4 *p = (const float4 *)(img + ((long)iy * W + ix) * CIN + cb * 16);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 t = p[q];
+                            v[q * 4] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                        for (int co = 0; co < CO; ++co)
+                            acc[co] = __builtin_fmaf(v[ci], w[((co * CIN + cb * 16 + ci) * K + ky) * K + kx], acc[co]);
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float v = pm::apply_act(acc[co], act, slope);
+            const long o = idx * CO + co;
+            if (res1) v = v + res1[o];
+            if (res2) v = v + res2[o];
+            y[o] = v;
+        }
+    }
+}
+
 // depthwise KxK, stride 1, pad K/2; NHWC, channel fastest
 __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                               float *y, int N, int H, int W, int C, int K) {
@@ -358,6 +456,37 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
     PM_LAUNCH(conv_smallcin_kernel, dim3(g), dim3(256), smem, (hipStream_t)stream, x, w, bias, res1, res2, y,
                        N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo, act, slope);
     return launch_ok();
+}
+
+extern "C" int pmctf_conv3x3_cin1_dual_f32(const float *x, const float *w, const float *bias, float *y, float *y2, int N,
+                                           int H, int W, int Cout, int act2, float slope, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cout != 16) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)N * H * W);
+    if (g > 16384) g = 16384;
+    PM_LAUNCH(conv3x3_cin1_pix16_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, y2, N, H, W, act2,
+              slope);
+    return launch_ok();
+}
+
+extern "C" int pmctf_conv2d_fewcout_supported(int Cin, int Cout, int K) {
+    return (K == 3 && Cin == 16 && Cout == 1) || (K == 3 && Cin == 64 && Cout == 1) || (K == 7 && Cin == 16 && Cout == 2);
+}
+
+extern "C" int pmctf_conv2d_fewcout_f32(const float *x, const float *w, const float *bias, const float *res1,
+                                        const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int K,
+                                        int act, float slope, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || !pmctf_conv2d_fewcout_supported(Cin, Cout, K)) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)N * H * W);
+    if (g > 16384) g = 16384;
+    hipStream_t st = (hipStream_t)stream;
+#define PM_FC(K_, CI_, CO_)                                                                                           \
+    PM_LAUNCH((conv_fewcout_pix_kernel<K_, CI_, CO_>), dim3(g), dim3(256), 0, st, x, w, bias, res1, res2, y, N, H, W,   \
+              act, slope);                                                                                            \
+    return launch_ok();
+    if (K == 3 && Cin == 16) { PM_FC(3, 16, 1) }
+    if (K == 3 && Cin == 64) { PM_FC(3, 64, 1) }
+    PM_FC(7, 16, 2)
+#undef PM_FC
 }
 
 extern "C" int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,

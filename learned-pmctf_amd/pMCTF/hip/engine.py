@@ -15,6 +15,7 @@ import math
 import threading
 from concurrent.futures import ThreadPoolExecutor
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -155,7 +156,7 @@ class HipEngine:
         # luma and chroma of a pair are independent once mv_hat exists: they are coded on two side streams so that
         # the small-plane kernels of one fill the tails of the other (per-stream LSTM state keeps them apart)
         self.side_streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
-        self.multi_stream = False       # measured: no gain (the big kernels already fill every SIMD's register file)
+        self.multi_stream = os.environ.get("PMCTF_MULTI_STREAM", "0") == "1"   # luma/chroma on two streams
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
 
@@ -195,8 +196,7 @@ class HipEngine:
         """x: plane (N,1,H,W) -> plane"""
         N, _, H, W = x.shape
         xin = x.view(N, H, W, 1)
-        c1 = self.conv(p + ".conv1", 1, 1)(xin)
-        t = as_nchw_ew(EW_TANH, c1)
+        c1, t = ops.conv3x3_cin1_dual(self.conv(p + ".conv1", 1, 1), xin, ACT_TANH)
         t = self.conv(p + ".conv2", 1, 1)(t, act=ACT_TANH)
         t = self.conv(p + ".conv3", 1, 1)(t, res1=c1)
         out = self.conv(p + ".conv4", 1, 1)(t)

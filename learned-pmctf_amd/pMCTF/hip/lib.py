@@ -24,6 +24,9 @@ _SIGS = {
     "pmctf_conv2d_nhwc_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
     "pmctf_conv2d_nhwc_geom_f32": (ci, [vp] * 6 + [ci] * 13 + [cf, vp]),
     "pmctf_conv2d_smallcin_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
+    "pmctf_conv3x3_cin1_dual_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
+    "pmctf_conv2d_fewcout_supported": (ci, [ci] * 3),
+    "pmctf_conv2d_fewcout_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
     "pmctf_dwconv2d_nhwc_f32": (ci, [vp] * 4 + [ci] * 5 + [vp]),
     "pmctf_flow_warp_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
     "pmctf_avgpool2_f32": (ci, [vp, vp, ci, ci, ci, vp]),

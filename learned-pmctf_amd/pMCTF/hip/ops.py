@@ -48,7 +48,10 @@ class Conv2d:
         self.pad = (int(padding[0]), int(padding[1])) if isinstance(padding, (tuple, list)) else (int(padding),) * 2
         self.small = self.Cin <= 4
         L = _lib.hip()
-        if self.small:
+        # one or two couts: vector-ALU kernel on plain OIHW weights (a matrix-core tile would be 15/16 empty)
+        self.few = (not self.small and self.stride == 1 and self.KH == self.KW and self.pad == (self.KH // 2,) * 2
+                    and bool(L.pmctf_conv2d_fewcout_supported(self.Cin, self.Cout, self.KH)))
+        if self.small or self.few:
             self.w = w.to(device)
             self.b = None if b is None else b.to(device)
         else:
@@ -83,6 +86,10 @@ class Conv2d:
         for r in (res1, res2):
             assert r is None or tuple(r.shape) == shp
         L = _lib.hip()
+        if self.few:
+            _lib.check(L.pmctf_conv2d_fewcout_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
+                                                  self.Cout, self.KH, int(act), float(slope), _stream()), "conv2d_fewcout")
+            return y
         fn = L.pmctf_conv2d_smallcin_f32 if self.small else L.pmctf_conv2d_nhwc_f32
         probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](self, x, self.stride)) else None
         if probe is not None:
@@ -95,6 +102,17 @@ class Conv2d:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))
         return y
+
+
+def conv3x3_cin1_dual(conv, x, act2):
+    """conv: a 1->16 3x3 'same' Conv2d; x (N,H,W,1).  Returns (conv(x), act2(conv(x))) from one launch."""
+    assert conv.small and conv.Cin == 1 and conv.Cout == 16 and conv.KH == 3 and conv.stride == 1 and conv.pad == (1, 1)
+    N, H, W, _ = x.shape
+    y = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y)
+    _lib.check(_lib.hip().pmctf_conv3x3_cin1_dual_f32(_p(x), _p(conv.w), _p(conv.b), _p(y), _p(y2), N, H, W, 16, int(act2),
+                                                      0.0, _stream()), "conv3x3_cin1_dual")
+    return y, y2
 
 
 class DepthwiseConv2d:

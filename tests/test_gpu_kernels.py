@@ -51,6 +51,8 @@ CONV_CASES = [
     (2, 1, 18, 16, 64, 3, 1, 1, 0, 0.0, 2),        # strip kernel: 1->64, one strip per row, two residual adds
     (1, 1, 20, 36, 128, 3, 1, 1, 3, 0.0, 0),       # strip kernel: 1->128 + tanh
     (1, 3, 17, 40, 192, 3, 1, 1, 0, 0.0, 1),       # strip kernel: 3->192 (3 cout groups -> 4 waves, one idle)
+    (2, 64, 37, 45, 1, 3, 1, 1, 0, 0.0, 1),        # few-cout kernel: PostProcess 64->1 with residual, 4 chunks
+    (1, 16, 33, 70, 1, 3, 1, 1, 2, 0.1, 2),        # few-cout kernel: 16->1, leaky, two residuals
 ]
 
 
@@ -168,3 +170,19 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
         for k, v in defaults.items():
             L.pmctf_conv2d_set_option(k.encode(), v)
     assert L.pmctf_conv2d_set_option(b"NO_SUCH_KNOB", 1) != 0
+
+
+def test_conv3x3_cin1_dual_output(cuda):
+    """PredictUpdate conv1: conv and tanh(conv) from one launch, both bit-exact"""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    r = _rng(5)
+    x = r.standard_normal((2, 1, 37, 70), dtype=np.float32) * 40
+    w = (r.standard_normal((16, 1, 3, 3), dtype=np.float32) * 0.1).astype(np.float32)
+    b = r.standard_normal(16, dtype=np.float32)
+    ref = clib.conv2d(x, w, b, 1, (1, 1))
+    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), 1, (1, 1))
+    y, y2 = ops.conv3x3_cin1_dual(conv, nhwc(x), ops.ACT_TANH)
+    torch.cuda.synchronize()
+    assert_same(nchw(y), ref, "conv1")
+    assert_same(nchw(y2), clib.tanh(ref), "tanh(conv1)")
