@@ -295,6 +295,61 @@ __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restri
     }
 }
 
+// depthwise 3x3 for C % 4 == 0: a thread owns 4 consecutive channels of a strip of PX consecutive pixels, keeps its
+// 36 weights in registers, reads the 3 x (PX+2) input window once as 16-byte loads and writes PX 16-byte stores.
+// Same sum order as dwconv_kernel: acc = bias; for ky: for kx: fmaf.
+template <int PX>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *y, int N, int H, int W,
+                                                            int C) {
+    const int C4 = C >> 2;
+    const int strips = (W + PX - 1) / PX;
+    const long total = (long)N * H * strips * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long r = idx / C4;
+        const int sx = (int)(r % strips) * PX;
+        r /= strips;
+        const int oy = (int)(r % H);
+        const long n = r / H;
+        float4 wr[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            wr[t] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+        const float4 b = bias ? *(const float4 *)(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) acc[j] = b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            const bool rowok = iy >= 0 && iy < H;
+            const float *row = x + ((n * H + (rowok ? iy : 0)) * W) * C + c;
+            float4 in[PX + 2];
+#pragma unroll
+            for (int j = 0; j < PX + 2; ++j) {
+                const int ix = sx + j - 1;
+                in[j] = (rowok && ix >= 0 && ix < W) ? *(const float4 *)(row + (long)ix * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 wt = wr[ky * 3 + kx];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    acc[j].x = __builtin_fmaf(in[j + kx].x, wt.x, acc[j].x);
+                    acc[j].y = __builtin_fmaf(in[j + kx].y, wt.y, acc[j].y);
+                    acc[j].z = __builtin_fmaf(in[j + kx].z, wt.z, acc[j].z);
+                    acc[j].w = __builtin_fmaf(in[j + kx].w, wt.w, acc[j].w);
+                }
+            }
+        }
+        float *o = y + ((n * H + oy) * W + sx) * C + c;
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+            if (sx + j < W) *(float4 *)(o + (long)j * C) = acc[j];
+    }
+}
+
 // flow warp: one thread per output pixel, loop over planes
 __global__ void flow_warp_kernel(const float *__restrict__ im, const float *__restrict__ flow,
                                  const float *__restrict__ lin_x, const float *__restrict__ lin_y, float *out,
@@ -492,6 +547,12 @@ extern "C" int pmctf_conv2d_fewcout_f32(const float *x, const float *w, const fl
 extern "C" int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int N, int H,
                                        int W, int C, int K, void *stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !(K & 1)) return PMCTF_EINVAL;
+    if (K == 3 && (C & 3) == 0) {
+        unsigned g4 = nblocks((long)N * H * ((W + 3) / 4) * (C / 4));
+        if (g4 > 16384) g4 = 16384;
+        PM_LAUNCH(dwconv3_strip_kernel<4>, dim3(g4), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C);
+        return launch_ok();
+    }
     unsigned g = nblocks((long)N * H * W * C);
     if (g > 16384) g = 16384;
     PM_LAUNCH(dwconv_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C, K);

@@ -97,13 +97,14 @@ def test_conv2d_denormals_and_specials(cuda):
     assert_same(nchw(y), ref, "denormal conv")
 
 
-def test_dwconv_bitexact(cuda):
+@pytest.mark.parametrize("shape", [(2, 64, 37, 51), (1, 112, 20, 36), (1, 6, 19, 23), (1, 192, 3, 2)])
+def test_dwconv_bitexact(cuda, shape):
     from pmctf_oracle import clib
     from pMCTF.hip import ops
     r = _rng(7)
-    x = r.standard_normal((2, 64, 37, 51), dtype=np.float32)
-    w = r.standard_normal((64, 1, 3, 3), dtype=np.float32)
-    b = r.standard_normal(64, dtype=np.float32)
+    x = r.standard_normal(shape, dtype=np.float32)
+    w = r.standard_normal((shape[1], 1, 3, 3), dtype=np.float32)
+    b = r.standard_normal(shape[1], dtype=np.float32)
     ref = clib.dwconv2d(x, w, b)
     y = ops.DepthwiseConv2d(torch.from_numpy(w), torch.from_numpy(b))(nhwc(x))
     assert_same(nchw(y), ref, "dwconv")
