@@ -496,6 +496,139 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Resident-patch variant for small planes (same arithmetic, same sum order): the workgroup stages the input patch of
+// its 4x16 tile for ALL input channels at once (one global-load latency instead of one per 16-channel chunk, a single
+// barrier), then every wave runs its 16 pixels x MT cout tiles straight through.  Small planes are latency-bound in
+// the chunked variants: a chunk's 36 MFMAs per wave are shorter than the load that feeds the next chunk.
+// Measured (tools/bench_conv.py, knob RES): with one cout tile per workgroup the 7x re-staged patch saturates L2->LDS
+// (56 vs 78 TFLOP/s on 144x240); with all cout tiles (RES=2) it wins only on 2x144x240 (93 vs 82).  Off by default.
+template <int MT>
+__global__ __launch_bounds__(256) void conv_mfma_res_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mtile0 = blockIdx.z * MT;
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = a.oy_base + ty * 4, ox0 = tx * 16;
+    const int LH = 3 * a.S + a.KH, LW = 15 * a.S + a.KW;
+    const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
+    const int taps = a.KH * a.KW;
+    const int CPR = a.Cin + 2;                // LDS pixel stride in words (even: 8-byte aligned rows of float2)
+    const int q4 = a.Cin >> 2;                // float4 units per pixel
+    const int E = LH * LW * q4;
+
+    // stage the whole patch; 8 loads in flight per thread and pass.  Element e = tid + 256*k is float4 `part` of patch
+    // pixel (ly, lx); the three indices advance incrementally (no divisions in the loop).
+    {
+        const int dpix = 256 / q4, dpart = 256 - dpix * q4;      // e += 256  ->  pix += dpix, part += dpart (+ carry)
+        const int drow = dpix / LW, dcol = dpix - drow * LW;      // pix += dpix ->  ly += drow, lx += dcol (+ carry)
+        int pix = tid / q4, part = tid - pix * q4;
+        int ly = pix / LW, lx = pix - ly * LW;
+        for (int e0 = 0; e0 < E; e0 += 256 * 8) {
+            f32x4 pre[8];
+            int spix[8], spart[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + tid + 256 * j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                spix[j] = pix; spart[j] = part;
+                if (e < E) {
+                    const int gy = iy0 + ly, gx = ix0 + lx;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + part * 4);
+                }
+                pre[j] = v;
+                part += dpart; pix += dpix; lx += dcol; ly += drow;
+                if (part >= q4) { part -= q4; ++pix; ++lx; }
+                if (lx >= LW) { lx -= LW; ++ly; }
+                if (lx >= LW) { lx -= LW; ++ly; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + tid + 256 * j;
+                if (e < E) {
+                    float2 *dst = (float2 *)(lds + spix[j] * CPR + spart[j] * 4);
+                    dst[0] = make_float2(pre[j].x, pre[j].y);
+                    dst[1] = make_float2(pre[j].z, pre[j].w);
+                }
+            }
+        }
+    }
+    f32x4 acc[MT];
+    {
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = *(const f32x4 *)(bp + mt * 16);
+    }
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * taps * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
+    const long wsteps = (long)a.ncb * taps;
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *(const f32x4 *)(wq + mt * 256);
+    const float *bl = lds + ((wave * a.S) * LW + (lane & 15) * a.S) * CPR + (lane >> 4);
+    __syncthreads();
+    long wstep = 0;
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        int ky = 0, kx = 0;
+        for (int tap = 0; tap < taps; ++tap) {
+            ++wstep;
+            {
+                const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
+            }
+            const float *bb = bl + (ky * LW + kx) * CPR + cb * CB;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+            const float b0 = bb[0], b1 = bb[4], b2 = bb[8], b3 = bb[12];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][0], b0, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][1], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][2], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][3], b3, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+        }
+    }
+
+    const int oy = oy0 + wave, ox = ox0 + (lane & 15);
+    if (oy >= a.oy_end || ox >= a.Wo) return;
+    const bool vec = (a.Cout & 3) == 0;
+    const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
+        if (co >= a.Cout) continue;
+        f32x4 v = acc[mt];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+        if (vec) {
+            if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+            if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+            *(f32x4 *)(a.y + pbase + co) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (co + i < a.Cout) {
+                    float s = v[i];
+                    if (a.res1) s = s + a.res1[pbase + co + i];
+                    if (a.res2) s = s + a.res2[pbase + co + i];
+                    a.y[pbase + co + i] = s;
+                }
+            }
+        }
+    }
+}
+
+
 // choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
 void choose_mt(int Cout, int &MT, int &MB) {
     const int tiles = (Cout + 15) / 16;
@@ -513,7 +646,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"V1", 0, false}, {"V2", 0, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"V1", 0, false}, {"V2", 0, false}};
 inline long knob(const char *name) {
     for (Knob &k : g_knobs)
         if (!strcmp(k.name, name)) {
@@ -581,6 +714,22 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     return pm_launch_status();
 }
 
+// resident-patch launch (4x16 tiles, MT cout tiles per workgroup); returns PMCTF_EINVAL when the patch does not fit
+template <int MT>
+int launch_res(const ConvArgs &a, int gz, hipStream_t st) {
+    ConvArgs b = a;
+    b.oy_base = 0;
+    b.oy_end = a.Ho;
+    b.tiles_x = (a.Wo + 15) / 16;
+    b.tiles_y = (a.Ho + 3) / 4;
+    const int LH = 3 * a.S + a.KH, LW = 15 * a.S + a.KW;
+    const size_t smem = (size_t)LH * LW * (a.Cin + 2) * sizeof(float);
+    if ((a.Cin % CB) != 0 || smem > 52 * 1024) return PMCTF_EINVAL;
+    dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
+    PM_LAUNCH((conv_mfma_res_kernel<MT>), grid, dim3(256), smem, st, b);
+    return pm_launch_status();
+}
+
 // MTP = cout tiles per packed M-block (fixed by the weight layout); chooses the tile shape and how the launch is cut.
 template <int MTP>
 int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
@@ -593,7 +742,17 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     // (1) small planes: too few 16-pixel segments to occupy 1024 SIMDs with whole M-blocks -> one cout tile per
     //     workgroup, MTP x more (and MTP x shorter) workgroups.  Same sums, same order.
     const long msplit_px = knob("MSPLIT_PX");
-    if (MTP >= 2 && px <= msplit_px) return launch<1, 1, 1>(a, MTP * MB, st, 0, a.Ho);
+    if (MTP >= 2 && px <= msplit_px) {
+        if (knob("RES") == 1) {
+            const int rc = launch_res<1>(a, MTP * MB, st);
+            if (rc != PMCTF_EINVAL) return rc;
+        }
+        if (knob("RES") == 2) {
+            const int rc = launch_res<MTP>(a, MB, st);
+            if (rc != PMCTF_EINVAL) return rc;
+        }
+        return launch<1, 1, 1>(a, MTP * MB, st, 0, a.Ho);
+    }
     // (2) large planes, stride 1: 8x32 tiles.  The wave-private kernel holds 2 workgroups per CU = 512 slots; rows
     //     that fill whole rounds of 512 go to it, the remaining rows (a partial round) are cut 4x finer (4x16 tiles)
     //     so the tail of the launch costs a quarter of a round instead of a full one.

@@ -155,11 +155,11 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2))
     xd = nhwc(x)
     L = lib.hip()
-    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0}
+    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0}
     settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
-                {"V2": 1, "MSPLIT_PX": 1 << 40}]
+                {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}]
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():
