@@ -62,6 +62,35 @@ class TorchK:
     def build_indexes(self, tables, scales):
         return tables.build_indexes_torch(scales)
 
+    # ---- estimate mode (gaussian_model.py:36-53,65-67) ------------------------------------------------------
+    def laplace_bits(self, y, sigma):
+        """CompressionModel.get_y_laplace_bits: the reference's own expressions"""
+        import math
+        mu = torch.zeros_like(sigma)
+        sigma = sigma.clamp(1e-5, 1e10)
+        lap = torch.distributions.laplace.Laplace(mu, sigma)
+        probs = lap.cdf(y + 0.5) - lap.cdf(y - 0.5)
+        bits = -1.0 * torch.log(probs + 1e-5) / math.log(2.0)
+        return torch.clamp_min(bits, 0)
+
+    def bitparm_cdf(self, x, params):
+        """BitEstimator.get_cdf (entropy_models.py:72-77,114-122); params = [(softplus(h), b, tanh(a) | None)] x 4"""
+        for sp_h, b, th_a in params:
+            x = x * sp_h + b
+            if th_a is not None:
+                x = x + torch.tanh(x) * th_a
+        return torch.sigmoid(x)
+
+    def z_bits(self, z, params):
+        import math
+        probs = self.bitparm_cdf(z + 0.5, params) - self.bitparm_cdf(z - 0.5, params)
+        bits = -1.0 * torch.log(probs + 1e-5) / math.log(2.0)
+        return torch.clamp_min(bits, 0)
+
+    def total(self, t):
+        """sum of a tensor of per-element bits / squared errors, as the reference takes it (f32 torch.sum)"""
+        return float(torch.sum(t))
+
 
 class CdefK(TorchK):
     name = "cdef"
@@ -101,3 +130,30 @@ class CdefK(TorchK):
 
     def build_indexes(self, tables, scales):
         return tables.build_indexes_cdef(scales)
+
+    # ---- estimate mode, PM-F32: every line one rounding; expm1(x) := pm_exp(x) - 1; totals are f64 sums ------------
+    def _neglog2(self, probs):
+        import math
+        bits = -1.0 * _t(clib.log((probs + 1e-5).numpy())) / math.log(2.0)
+        return torch.clamp_min(bits, 0)
+
+    def laplace_bits(self, y, sigma):
+        sigma = sigma.clamp(1e-5, 1e10)
+
+        def cdf(v):
+            e = _t(clib.exp((-v.abs() / sigma).numpy())) - 1.0
+            return 0.5 - 0.5 * v.sign() * e
+        return self._neglog2(cdf(y + 0.5) - cdf(y - 0.5))
+
+    def bitparm_cdf(self, x, params):
+        for sp_h, b, th_a in params:
+            x = x * sp_h + b
+            if th_a is not None:
+                x = x + self.tanh(x.contiguous()) * th_a
+        return self.sigmoid(x.contiguous())
+
+    def z_bits(self, z, params):
+        return self._neglog2(self.bitparm_cdf(z + 0.5, params) - self.bitparm_cdf(z - 0.5, params))
+
+    def total(self, t):
+        return float(t.double().sum())

@@ -281,7 +281,7 @@ class Oracle:
             x = self.depth_conv_block(f"mv_y_spatial_prior.{s}.{i}", x)
         return x.chunk(8, 1)
 
-    def compress_four_part_prior(self, s, y, common_params):
+    def compress_four_part_prior(self, s, y, common_params, full=False):
         """MVCoderQuad.forward_four_part_prior(write=True), four_part_prior.py:89-208 (enc_dec_quant=True)"""
         quant_step, scales, means = common_params.chunk(3, 1)
         quant_step = torch.max(quant_step, torch.ones_like(quant_step) * 0.5)      # LowerBound, video_net.py:14-20
@@ -323,6 +323,12 @@ class Oracle:
         qw = [q00 + q11 + q22 + q33, q03 + q12 + q21 + q30, q02 + q13 + q20 + q31, q01 + q10 + q23 + q32]
         sw = [sh00 + sh11 + sh22 + sh33, sh03 + sh12 + sh21 + sh30, sh02 + sh13 + sh20 + sh31,
               sh01 + sh10 + sh23 + sh32]
+        if full:    # write=False outputs: combine_four_parts of the quantised residuals and of the scales (:80-87,177-192)
+            y_q = torch.cat((q00 + q01 + q02 + q03, q10 + q11 + q12 + q13, q20 + q21 + q22 + q23,
+                             q30 + q31 + q32 + q33), dim=1)
+            scales_hat = torch.cat((sh00 + sh01 + sh02 + sh03, sh10 + sh11 + sh12 + sh13, sh20 + sh21 + sh22 + sh23,
+                                    sh30 + sh31 + sh32 + sh33), dim=1)
+            return y_q, y_hat, scales_hat
         return qw, sw, y_hat
 
     # ------------------------------------------------------------------ entropy hand-off (a16)
@@ -851,5 +857,157 @@ class _DecoderMixin:
 
 
 for _n, _f in list(vars(_DecoderMixin).items()):
+    if callable(_f) and not _n.startswith("__"):
+        setattr(Oracle, _n, _f)
+
+
+class _EstimateMixin:
+    """Estimate-mode forward: pMCTF.forward_one_stage / pWave.forward_one_channel with Laplace bit
+    estimates instead of range coding (pMCTF_L.py:244-295,332-379; pWave.py:231-312; gaussian_model.py:36-67).
+    Scalars come back as Python floats: with the ATen back-end they are the reference's own f32 reductions, with the
+    PM-F32 back-end f64 sums of per-element f32 values (the product's definition)."""
+
+    def bitparm_params(self, s):
+        out = []
+        for i in (1, 2, 3, 4):
+            pre = f"mv_bit_est.{s}.f{i}."
+            a = self.sd.get(pre + "a")
+            out.append((F.softplus(self.sd[pre + "h"]), self.sd[pre + "b"], None if a is None else torch.tanh(a)))
+        return out
+
+    def mse(self, a, b):
+        if self.K.name == "torch":
+            return float(F.mse_loss(a, b, reduction="mean"))
+        d = a - b
+        return self.K.total(d * d) / d.numel()
+
+    def pwave_forward(self, coder, x, q_index=None, qp_scale=None):
+        """pWave.forward -> forward_one_channel (pWave.py:231-312)"""
+        if q_index is None:
+            q_scale, q_scale_ll = self.sd[f"{coder}.QP"][-1], self.sd[f"{coder}.QP_ll"][-1]
+        else:
+            q_scale = get_curr_q(self.sd[f"{coder}.QP"], q_index)
+            q_scale_ll = get_curr_q(self.sd[f"{coder}.QP_ll"], q_index)
+            if qp_scale is not None:
+                q_scale = q_scale * qp_scale
+                q_scale_ll = q_scale_ll * qp_scale
+        clip = 8192.
+        y = {}
+        ll = x
+        for lvl in range(self.L):
+            y[lvl] = self.forward_lift_2d(coder, ll)
+            ll = y[lvl]["ll"]
+        subbands_hat = {lvl: {} for lvl in range(self.L)}
+        ll = (ll * q_scale_ll).clamp(-clip, clip)
+        ll_hat = torch.round(ll)
+        params = self.context_fusion_ll(coder, ll_hat)
+        scales, means = params.chunk(2, dim=1)
+        bits_ll = self.K.laplace_bits(ll_hat - means, scales)
+        subbands_hat[self.L - 1]["ll"] = ll_hat
+        N = x.size(0)
+        if self.K.name == "torch":
+            bits_total = torch.sum(bits_ll, dim=(1, 2, 3))
+        else:
+            bits_total = bits_ll.double().sum(dim=(1, 2, 3))
+        self.ctx_init(list(ll.size()))
+        context = self.ctx_forward_one_subband(coder, ll_hat, "ll", self.L - 1)
+        for lvl in range(self.L - 1, -1, -1):
+            for sidx, sb in enumerate(["lh", "hl", "hh"]):
+                ctx = context.chunk(3, dim=1)[sidx]
+                prev = subbands_hat[lvl + 1][sb] if lvl < self.L - 1 else None
+                s_curr = (y[lvl][sb] * q_scale).clamp(-clip, clip)
+                qs, ss, s_hat = self.fusion_compress(f"{coder}.context_fusion.{lvl}.{sb}", s_curr, ctx, prev)
+                subbands_hat[lvl][sb] = s_hat
+                s_q = qs[0] + qs[1] + qs[2] + qs[3]
+                sc = ss[0] + ss[1] + ss[2] + ss[3]
+                bits = self.K.laplace_bits(s_q, sc)
+                if self.K.name == "torch":
+                    bits_total += torch.sum(bits, dim=(1, 2, 3))
+                else:
+                    bits_total = bits_total + bits.double().sum(dim=(1, 2, 3))
+                context = self.ctx_forward_one_subband(coder, s_hat, sb, lvl)
+        rec = {lvl: {} for lvl in range(self.L)}
+        for lvl in range(self.L - 1, -1, -1):
+            for sb in (["ll", "lh", "hl", "hh"] if lvl == self.L - 1 else ["lh", "hl", "hh"]):
+                rec[lvl][sb] = subbands_hat[lvl][sb] / (q_scale_ll if sb == "ll" else q_scale)
+        out = None
+        for lvl in range(self.L - 1, -1, -1):
+            out = self.backward_lift_2d(coder, rec[lvl])
+            if lvl > 0:
+                rec[lvl - 1]["ll"] = out
+        x_hat = self.post_process(coder, out / 256.0) * 256.0
+        tot = bits_total.sum()
+        return {"x_hat": x_hat, "subbands": subbands_hat, "bits_per_plane": [float(b) for b in bits_total],
+                "bpp_total": float(tot / (x_hat.size(2) * x_hat.size(3) * x_hat.size(0))),
+                "bits_total": float(tot / x_hat.size(0)), "mse": self.mse(x, x_hat)}
+
+    def forward_four_part_prior(self, s, y, common_params):
+        """MVCoderQuad.forward_four_part_prior(write=False): (y_q, y_hat, scales_hat), four_part_prior.py:89-195"""
+        return self.compress_four_part_prior(s, y, common_params, full=True)
+
+    def compute_and_code_motion(self, ref_frame, cur_frame, q_index, dpb, stage_idx=0):
+        """pMCTF_L.py:244-292 at inference (me_downsample=1)"""
+        s = min(self.num_me_stages - 1, stage_idx)
+        q_enc = get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index)          # not rounded here (inference=False)
+        q_dec = get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index)
+        mv_cur = cur_frame[0, :, :, :].tile((1, 3, 1, 1)) / 255
+        mv_ref = ref_frame[0, :, :, :].tile((1, 3, 1, 1)) / 255
+        est_mv = self.spynet(mv_cur, mv_ref)
+        mv_y = self.mv_enc(s, est_mv, dpb["mv_feature"], q_enc)
+        mv_z = self.mv_hyper_enc(s, mv_y)
+        mv_z_hat = torch.round(mv_z)
+        mv_params = self.mv_prior_param_decoder(mv_z_hat, dpb, s)
+        mv_y_q, mv_y_hat, mv_scales_hat = self.forward_four_part_prior(s, mv_y, mv_params)
+        mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        bits_y = self.K.laplace_bits(mv_y_q, mv_scales_hat)
+        bits_z = self.K.z_bits(mv_z_hat, self.bitparm_params(s))
+        pixel_num = ref_frame.size(2) * ref_frame.size(3)
+        if self.K.name == "torch":
+            bpp_y = float(torch.sum(torch.sum(bits_y, dim=(1, 2, 3)) / pixel_num))
+            bpp_z = float(torch.sum(torch.sum(bits_z, dim=(1, 2, 3)) / pixel_num))
+        else:
+            bpp_y = self.K.total(bits_y) / pixel_num
+            bpp_z = self.K.total(bits_z) / pixel_num
+        return mv_hat, {"mv_feature": mv_feature, "mv_y_hat": mv_y_hat}, bpp_y, bpp_z
+
+    def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0):
+        """pMCTF_L.py:332-379"""
+        if mv_hat is not None:
+            bpp_y = bpp_z = None
+            ref_mv = {"mv_feature": None, "mv_y_hat": None}
+            mv_hat = self.K.bilinear_down2(mv_hat) / 2
+        else:
+            mv_hat, ref_mv, bpp_y, bpp_z = self.compute_and_code_motion(ref_frame, cur_frame, q_index, dpb, stage_idx)
+        L_t, H_t, pred, inv = self.forward_MCTF(ref_frame, cur_frame, mv_hat, stage_idx)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        res_H = self.pwave_forward("hp_coder", H_t, q_index, qp_scale)
+        pix = ref_frame.size(2) * ref_frame.size(3)
+        f32 = (lambda v: float(np.float32(v))) if self.K.name == "torch" else (lambda v: v)
+        ret = {"bpp_mv_y": bpp_y, "bpp_mv_z": bpp_z,
+               "bpp_me": None if bpp_z is None else f32(np.float32(bpp_z) + np.float32(bpp_y)) if self.K.name == "torch"
+               else bpp_z + bpp_y,
+               "me_mse": self.mse(pred, cur_frame), "bpp_H": res_H["bpp_total"], "bit_H": res_H["bits_total"],
+               "mse_H": res_H["mse"], "mv_hat": mv_hat,
+               "dpb": {"mv_feature": ref_mv["mv_feature"], "ref_mv_y": ref_mv["mv_y_hat"]}, "H_t": res_H["x_hat"]}
+        if self.K.name == "torch":
+            t = torch.tensor
+            bpp = t(res_H["bpp_total"]) if bpp_z is None else t(res_H["bpp_total"]) + t(bpp_z) + t(bpp_y)
+            ret["bpp"] = float(bpp)
+            ret["bit_ME"] = None if bpp_z is None else float((t(bpp_y) + t(bpp_z)) * pix)
+            ret["bit"] = float(bpp * pix)
+        else:
+            ret["bpp"] = res_H["bpp_total"] if bpp_z is None else res_H["bpp_total"] + bpp_z + bpp_y
+            ret["bit_ME"] = None if bpp_z is None else (bpp_y + bpp_z) * pix
+            ret["bit"] = ret["bpp"] * pix
+        if code_lt:
+            res_L = self.pwave_forward("lp_coder", L_t, q_index)
+            ret.update({"bpp_L": res_L["bpp_total"], "bit_L": res_L["bits_total"], "mse_L": res_L["mse"],
+                        "me_mse_inv": self.mse(inv, ref_frame), "L_t": res_L["x_hat"]})
+        else:
+            ret["L_t"] = L_t
+        return ret
+
+
+for _n, _f in list(vars(_EstimateMixin).items()):
     if callable(_f) and not _n.startswith("__"):
         setattr(Oracle, _n, _f)

@@ -72,3 +72,37 @@ def test_gop4_bits_and_psnr_torch_backend(sd):
         cur = int(g[f"gop.pair{i}.meta"][2])
         for name, key in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin")):
             assert r["files"][name] == g[f"gop.pair{i}.file.{key}"].tobytes()
+
+
+@pytest.mark.parametrize("backend,rtol,ttol", [("torch", 1e-6, 1e-4), ("cdef", 2e-5, 2e-3)])
+def test_estimate_mode_forward(sd, backend, rtol, ttol):
+    """forward_one_stage (bit ESTIMATES instead of range coding, pMCTF_L.py:332-379) against the real reference's
+    outputs: luma pair with motion estimation and L coding, chroma pair driven by the luma motion, and a pair without
+    L coding whose MV codec uses the dpb of a previous pair.  Scalars relative, tensors absolute."""
+    from pmctf_oracle.model import Oracle
+    g = golden()
+    o = Oracle(sd, 1, backend)
+    (Y0, C0), (Y1, C1) = frames(W, H, 2)
+    with torch.no_grad():
+        dpb = {"mv_feature": None, "ref_mv_y": None}
+        ry = o.forward_one_stage(Y0, Y1, 3, True, dpb)
+        rc = o.forward_one_stage(C0, C1, 3, True, dpb, mv_hat=ry["mv_hat"])
+        rn = o.forward_one_stage(Y0, Y1, 12, False, ry["dpb"], stage_idx=0)
+    checked = 0
+    for tag, d in (("y", ry), ("c", rc), ("n", rn)):
+        for k, v in d.items():
+            if k == "dpb":
+                for kk, vv in v.items():
+                    if vv is not None:
+                        assert _close(vv, g[f"est.{tag}.dpb.{kk}"], ttol), (tag, kk)
+                continue
+            key = f"est.{tag}.{k}"
+            if v is None:
+                assert key not in g.files, key
+            elif isinstance(v, torch.Tensor):
+                assert _close(v, g[key], ttol), key
+            else:
+                ref = float(g[key])
+                assert abs(v - ref) <= rtol * max(1.0, abs(ref)), (key, v, ref)
+                checked += 1
+    assert checked == sum(1 for k in g.files if k.startswith("est.") and g[k].shape == ()) == 34

@@ -198,6 +198,20 @@ def main():
             out["dec.mv_feature"] = r["dpb"]["mv_feature"].numpy().copy()
             out["dec.bits"] = np.array([r["bit_H"], r["bit_L"], r["bit_ME"]], np.float64)
 
+        # ---- estimate-mode forward (pMCTF_L.py:332-379): luma with motion estimation, chroma with the luma motion ------
+        dpb = {"mv_feature": None, "ref_mv_y": None}
+        ry = net.forward_one_stage(Y0, Y1, 3, True, dpb)
+        rc = net.forward_one_stage(C0, C1, 3, True, dpb, mv_hat=ry["mv_hat"])
+        rn = net.forward_one_stage(Y0, Y1, 12, False, ry["dpb"], stage_idx=0)      # no L coding, dpb from a coded pair
+        for tag, d in (("y", ry), ("c", rc), ("n", rn)):
+            for k, v in d.items():
+                if k == "dpb":
+                    for kk, vv in v.items():
+                        if vv is not None:
+                            out[f"est.{tag}.dpb.{kk}"] = vv.numpy().copy()
+                elif v is not None:
+                    out[f"est.{tag}.{k}"] = np.asarray(v.detach().numpy()).copy()
+
     path = os.path.join(args.out, f"reference_{W}x{H}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}.meta.json"), "w"), indent=1)
