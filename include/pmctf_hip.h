@@ -209,6 +209,30 @@ int pmctf_mv_fourpart_dequant_f32(const int16_t *sym, const float *common, const
 /* decoded int16 symbols [C][HW] -> float NHWC [HW][C] (mv_z_hat, pMCTF_L.py:504-505) */
 int pmctf_sym_to_nhwc_f32(const int16_t *sym, float *out, int HW, int C, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Estimate-mode forward (pMCTF.forward_one_stage, pMCTF_L.py:332-379; pWave.forward_one_channel, pWave.py:243-312):
+ * Laplace / factorized bit ESTIMATES (gaussian_model.py:36-53,65-67) and squared-error sums instead of range coding.
+ * Per element: sigma = clamp(s, 1e-5, 1e10); cdf(v) = 0.5 - 0.5*sign(v)*(exp(-|v|/sigma) - 1);
+ * bits = max(-log2(cdf(y+0.5) - cdf(y-0.5) + 1e-5), 0) in f32; totals are f64 sums.  Every function ADDS to device
+ * doubles the caller has zeroed. */
+
+/* step k of ContextFusionFourStep.forward (context_fusion_4step.py:156-186): writes x_hat at the class-k positions
+ * of so_far (zeroes the rest when k == 0) and adds their bits to bits_per_plane[n].  Layouts as pmctf_fourstep_quant_f32. */
+int pmctf_fourstep_estimate_f32(const float *x, const float *params, float *so_far, int N, int H, int W, int k,
+                                int params_sub, double *bits_per_plane, void *stream);
+/* LL subband (pWave.py:255-263): bits of ll_hat - mean (not rounded again) under scale; params [N*HW][2]. */
+int pmctf_ll_estimate_f32(const float *ll_hat, const float *params, int N, int64_t HW, double *bits_per_plane,
+                          void *stream);
+/* MV hyper latent (pMCTF_L.py:262,283; entropy_models.py:72-77,114-122): z_hat = round(z) (NHWC [HW][C]) and the bits
+ * of the factorized prior; consts [11][C] = softplus(h) of f1..f4, b of f1..f4, tanh(a) of f1..f3. */
+int pmctf_z_estimate_f32(const float *z, float *z_hat, const float *consts, int64_t HW, int C, double *bits,
+                         void *stream);
+/* step t of MVCoderQuad.forward_four_part_prior (four_part_prior.py:89-195); layouts as pmctf_mv_fourpart_step_f32. */
+int pmctf_mv_fourpart_estimate_f32(const float *y, const float *common, const float *sp, float *so_far, int H, int W,
+                                   int t, double *bits, void *stream);
+/* nn.MSELoss numerator: sum += sum((a[i]-b[i])^2) */
+int pmctf_sqdiff_sum_f32(const float *a, const float *b, int64_t n, double *sum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

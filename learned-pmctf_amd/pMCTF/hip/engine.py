@@ -78,6 +78,14 @@ class SymbolStream:
         return hs, hi, ev
 
 
+class BitSink:
+    """Estimate mode: where a SymbolStream collects symbols for the range coder, a BitSink collects the Laplace bit
+    estimates of the same elements (device float64, one accumulator per plane)."""
+
+    def __init__(self, planes, device):
+        self.bits = torch.zeros(planes, dtype=torch.float64, device=device)
+
+
 class RangeCoderPool:
     """Host range coding overlapped with GPU work: one job = one bitstream file.  ctypes releases the GIL
     inside libpmctf_rans.so, so streams are coded in parallel on worker threads."""
@@ -341,10 +349,13 @@ class HipEngine:
         params = self.depth_conv_block(f"mv_y_prior_fusion.{s}.0", params)
         return self.depth_conv_block(f"mv_y_prior_fusion.{s}.1", params)
 
-    def get_mv_y_q(self, q_index, s):
-        enc, _ = get_rounded_q(get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index).numpy())
-        dec, _ = get_rounded_q(get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index).numpy())
-        return enc, dec
+    def get_mv_y_q(self, q_index, s, inference=True):
+        """pMCTF_L.py:221-231; the estimate-mode forward does not round the steps to two decimals"""
+        enc = get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index)
+        dec = get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index)
+        if not inference:
+            return float(enc), float(dec)
+        return get_rounded_q(enc.numpy())[0], get_rounded_q(dec.numpy())[0]
 
     def to_nhwc_input(self, t):
         """dpb tensors come back from the caller as logical NCHW; accept channels-last or planar storage."""
@@ -359,16 +370,39 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ a2 compress_mv (pMCTF_L.py:448-495)
-    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0):
+    def bitparm_consts(self, s):
+        """per-channel constants of the factorized prior (entropy_models.py:72-77), evaluated on the host like the
+        other scalar parameters: rows softplus(h) f1..f4, b f1..f4, tanh(a) f1..f3"""
+        if not hasattr(self, "_bitparm"):
+            self._bitparm = {}
+        c = self._bitparm.get(s)
+        if c is None:
+            import torch.nn.functional as F
+            g = lambda i, n: self.sd[f"mv_bit_est.{s}.f{i}.{n}"].reshape(-1)
+            rows = [F.softplus(g(i, "h")) for i in (1, 2, 3, 4)] + [g(i, "b") for i in (1, 2, 3, 4)] + \
+                   [torch.tanh(g(i, "a")) for i in (1, 2, 3)]
+            c = torch.stack(rows).contiguous().to(self.dev)
+            torch.cuda.synchronize(self.dev)
+            self._bitparm[s] = c
+        return c
+
+    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0, estimate=False):
+        """estimate=True: compute_and_code_motion (pMCTF_L.py:244-292): same networks, unrounded quantisation steps,
+        bit estimates (two device float64: y, z) instead of a symbol stream"""
         s = min(self.num_me_stages - 1, stage_idx)
-        q_enc, q_dec = self.get_mv_y_q(q_index, s)
+        q_enc, q_dec = self.get_mv_y_q(q_index, s, inference=not estimate)
         est_mv = self.spynet(cur_y, ref_y)
         mv_y = self.mv_enc(s, est_mv, self.to_nhwc_input(dpb["mv_feature"]), q_enc)
         mv_z = self.mv_hyper_enc(s, mv_y)
         _, hy, wy, _ = mv_y.shape
         _, hz, wz, cz = mv_z.shape
-        stream = SymbolStream(hz * wz * cz + 4 * 16 * hy * wy, self.dev)
-        z_hat = ops.z_symbols(mv_z, stream.sym, stream.idx, stream.take(hz * wz * cz, f"z{s}"))
+        if estimate:
+            stream = None
+            bits_y, bits_z = BitSink(1, self.dev), BitSink(1, self.dev)
+            z_hat = ops.z_estimate(mv_z, self.bitparm_consts(s), bits_z.bits)
+        else:
+            stream = SymbolStream(hz * wz * cz + 4 * 16 * hy * wy, self.dev)
+            z_hat = ops.z_symbols(mv_z, stream.sym, stream.idx, stream.take(hz * wz * cz, f"z{s}"))
         common = self.mv_prior_param_decoder(z_hat, self.to_nhwc_input(dpb["ref_mv_y"]), s)
         so_far = torch.empty_like(mv_y)
         sp = None
@@ -378,12 +412,18 @@ class HipEngine:
                 for i in range(3):
                     x = self.depth_conv_block(f"mv_y_spatial_prior.{s}.{i}", x)
                 sp = x
-            ops.mv_fourpart_step(mv_y, common, sp, so_far, stream.sym, stream.idx, stream.take(16 * hy * wy, "gauss"),
-                                 t, self.lmin, self.lstep)
+            if estimate:
+                ops.mv_fourpart_estimate(mv_y, common, sp, so_far, t, bits_y.bits)
+            else:
+                ops.mv_fourpart_step(mv_y, common, sp, so_far, stream.sym, stream.idx,
+                                     stream.take(16 * hy * wy, "gauss"), t, self.lmin, self.lstep)
         mv_y_hat = ops.mv_dequant(so_far, common)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
-        return {"stream": stream, "mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat,
-                "est_mv": est_mv, "mv_y": mv_y, "z_hat": z_hat, "common": common}
+        out = {"stream": stream, "mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat,
+               "est_mv": est_mv, "mv_y": mv_y, "z_hat": z_hat, "common": common}
+        if estimate:
+            out["bits_y"], out["bits_z"] = bits_y.bits, bits_z.bits
+        return out
 
     # ------------------------------------------------------------------ a10 learned lifting DWT
     def lift_branch(self, wt, conv_name, pu_name, x):
@@ -472,7 +512,7 @@ class HipEngine:
         params = self.depth_conv_block(p + ".y_hierarchical_prior_out", c)
         so_far = torch.empty_like(x)
         n = N * H * W
-        ops.fourstep_quant(x, params, so_far, stream.sym, stream.idx, stream.take(n, "gauss"), 0, self.lmin, self.lstep)
+        self._fourstep(stream, x, params, so_far, 0, n)
         for step in (1, 2, 3):
             t = self.conv(f"{p}.y_spatial_prior_{step}.0", 1, 1)(so_far.view(N, H, W, 1))
             t = self.context_residual(f"{p}.y_spatial_prior_{step}.1", t, res2=c)      # (.. + x) + context
@@ -490,9 +530,14 @@ class HipEngine:
             else:
                 t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
                 params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
-            ops.fourstep_quant(x, params, so_far, stream.sym, stream.idx, stream.take(n, "gauss"), step, self.lmin,
-                               self.lstep)
+            self._fourstep(stream, x, params, so_far, step, n)
         return so_far
+
+    def _fourstep(self, sink, x, params, so_far, step, n):
+        if isinstance(sink, BitSink):
+            ops.fourstep_estimate(x, params, so_far, step, sink.bits)
+        else:
+            ops.fourstep_quant(x, params, so_far, sink.sym, sink.idx, sink.take(n, "gauss"), step, self.lmin, self.lstep)
 
     # ------------------------------------------------------------------ a13 conv-LSTM context (long_context.py)
     def lstm(self, p, x, state):
@@ -556,9 +601,18 @@ class HipEngine:
                 q_scale_ll = q_scale_ll * qp_scale
         return float(q_scale), float(q_scale_ll)
 
-    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False):
+    def pwave_forward(self, coder, x, q_index, qp_scale=None):
+        """pWave.forward_one_channel (pWave.py:243-312): the coder's networks with bit ESTIMATES.  Returns a dict with
+        x_hat (plane), subbands (quantised), bits (device float64 per plane), sq_err (device float64 scalar)."""
+        x_hat, sink, hat = self.pwave_compress(coder, x, q_index, qp_scale, estimate=True)
+        sq = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        ops.sqdiff_sum(x.contiguous(), x_hat, sq)
+        return {"x_hat": x_hat, "subbands": hat, "bits": sink.bits, "sq_err": sq}
+
+    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False, estimate=False):
         """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream).  ar_order: LL symbols in the sequential coder's
-        order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555)."""
+        order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555).
+        estimate=True: returns (x_hat, BitSink, quantised subbands) — see pwave_forward."""
         q_scale, q_scale_ll = self.q_scales(coder, q_index, qp_scale)
         N, _, H, W = x.shape
         clip = 8192.0
@@ -567,12 +621,16 @@ class HipEngine:
         for lvl in range(self.L):
             y[lvl] = self.forward_lift_2d(coder, ll)
             ll = y[lvl]["ll"]
-        stream = SymbolStream(self.pwave_symbol_count(N, H, W), self.dev)
+        stream = BitSink(N, self.dev) if estimate else SymbolStream(self.pwave_symbol_count(N, H, W), self.dev)
         hat = {lvl: {} for lvl in range(self.L)}
         llq = ew(EW_ROUND_CLAMP_MULS, ll, alpha=q_scale_ll, beta=clip)
         params = self.context_fusion_ll(coder, llq)
-        ll_hat = ops.ll_quant(llq, params, stream.sym, stream.idx, stream.take(llq.numel(), "gauss"), self.lmin,
-                              self.lstep, ar_order)
+        if estimate:        # pWave.py:255-263: the rounded LL itself is kept; bits of the unrounded residual
+            ops.ll_estimate(llq, params, stream.bits)
+            ll_hat = llq
+        else:
+            ll_hat = ops.ll_quant(llq, params, stream.sym, stream.idx, stream.take(llq.numel(), "gauss"), self.lmin,
+                                  self.lstep, ar_order)
         hat[self.L - 1]["ll"] = ll_hat
         lstm_state = self.ctx_init(N, ll.shape[2], ll.shape[3])
         context = self.ctx_forward_one_subband(coder, lstm_state, ll_hat, "ll", self.L - 1)
@@ -595,7 +653,37 @@ class HipEngine:
             out = self.backward_lift_2d(coder, sbs)
             rec_ll = out
         x_hat = self.post_process(coder, out, 256.0, 256.0)
+        if estimate:
+            return x_hat, stream, hat
         return x_hat, stream
+
+    # ------------------------------------------------------------------ estimate-mode stage (pMCTF_L.py:332-379)
+    def forward_one_stage(self, ref, cur, q_index, code_lt, dpb, mv_hat=None, stage_idx=0):
+        """Returns tensors plus a dict `acc` of device float64 accumulators; the caller turns them into the
+        reference's bpp / mse scalars with ONE synchronising read."""
+        acc = {}
+        if mv_hat is not None:
+            mv_hat = ops.bilinear_down2(mv_hat, 2.0)
+            ref_mv = {"mv_feature": None, "mv_y_hat": None}
+        else:
+            mv = self.compress_mv(ref[0:1], cur[0:1], dpb, stage_idx=stage_idx, q_index=q_index, estimate=True)
+            mv_hat = mv["mv_hat"]
+            ref_mv = mv
+            acc["bits_mv_y"], acc["bits_mv_z"] = mv["bits_y"], mv["bits_z"]
+        L_t, H_t, pred, inv = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        res_H = self.pwave_forward("hp_coder", H_t, q_index, qp_scale)
+        acc["bits_H"], acc["sq_H"] = res_H["bits"], res_H["sq_err"]
+        acc["sq_me"] = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        ops.sqdiff_sum(pred, cur.contiguous(), acc["sq_me"])
+        out = {"mv_hat": mv_hat, "ref_mv": ref_mv, "H_t": res_H["x_hat"], "L_t": L_t, "acc": acc}
+        if code_lt:
+            res_L = self.pwave_forward("lp_coder", L_t, q_index)
+            acc["bits_L"], acc["sq_L"] = res_L["bits"], res_L["sq_err"]
+            acc["sq_me_inv"] = torch.zeros(1, dtype=torch.float64, device=self.dev)
+            ops.sqdiff_sum(inv, ref.contiguous(), acc["sq_me_inv"])
+            out["L_t"] = res_L["x_hat"]
+        return out
 
     # ------------------------------------------------------------------ a8 compress_one_stage (pMCTF_L.py:398-420)
     def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0, ar_order=False):

@@ -27,6 +27,11 @@ _SIGS = {
     "pmctf_conv3x3_cin1_dual_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
     "pmctf_conv2d_fewcout_supported": (ci, [ci] * 3),
     "pmctf_conv2d_fewcout_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
+    "pmctf_fourstep_estimate_f32": (ci, [vp] * 3 + [ci] * 5 + [vp, vp]),
+    "pmctf_ll_estimate_f32": (ci, [vp, vp, ci, i64, vp, vp]),
+    "pmctf_z_estimate_f32": (ci, [vp, vp, vp, i64, ci, vp, vp]),
+    "pmctf_mv_fourpart_estimate_f32": (ci, [vp] * 4 + [ci] * 3 + [vp, vp]),
+    "pmctf_sqdiff_sum_f32": (ci, [vp, vp, i64, vp, vp]),
     "pmctf_dwconv2d_nhwc_f32": (ci, [vp] * 4 + [ci] * 5 + [vp]),
     "pmctf_flow_warp_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
     "pmctf_avgpool2_f32": (ci, [vp, vp, ci, ci, ci, vp]),

@@ -366,3 +366,44 @@ def mv_dequant(so_far, common):
     _lib.check(_lib.hip().pmctf_mv_dequant_f32(_p(so_far), _p(common), _p(y_hat), so_far.shape[1] * so_far.shape[2],
                                                _stream()), "mv_dequant")
     return y_hat
+
+
+# ------------------------------------------------------------------------------------------------
+# estimate mode (bit estimates / squared errors accumulate into device float64 tensors)
+def _pd(t):
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def fourstep_estimate(x, params, so_far, k, bits):
+    N, _, H, W = x.shape
+    sub = 0 if params.shape[1] == H else 1
+    assert params.shape[1] * (1 + sub) == H and params.shape[2] * (1 + sub) == W and bits.numel() == N
+    _lib.check(_lib.hip().pmctf_fourstep_estimate_f32(_p(x), _p(params), _p(so_far), N, H, W, k, sub, _pd(bits),
+                                                      _stream()), "fourstep_estimate")
+
+
+def ll_estimate(ll_hat, params, bits):
+    N, _, H, W = ll_hat.shape
+    assert bits.numel() == N
+    _lib.check(_lib.hip().pmctf_ll_estimate_f32(_p(ll_hat), _p(params), N, H * W, _pd(bits), _stream()), "ll_estimate")
+
+
+def z_estimate(z, consts, bits):
+    N, H, W, Cc = z.shape
+    assert N == 1 and tuple(consts.shape) == (11, Cc)
+    z_hat = torch.empty_like(z)
+    _lib.check(_lib.hip().pmctf_z_estimate_f32(_p(z), _p(z_hat), _p(consts), H * W, Cc, _pd(bits), _stream()), "z_estimate")
+    return z_hat
+
+
+def mv_fourpart_estimate(y, common, sp, so_far, t, bits):
+    N, H, W, Cc = y.shape
+    assert N == 1 and Cc == 64
+    _lib.check(_lib.hip().pmctf_mv_fourpart_estimate_f32(_p(y), _p(common), _p(sp), _p(so_far), H, W, t, _pd(bits),
+                                                         _stream()), "mv_fourpart_estimate")
+
+
+def sqdiff_sum(a, b, acc):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    _lib.check(_lib.hip().pmctf_sqdiff_sum_f32(_p(a), _p(b), a.numel(), _pd(acc), _stream()), "sqdiff_sum")

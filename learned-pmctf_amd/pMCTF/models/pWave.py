@@ -76,6 +76,24 @@ class pWave(nn.Module):
         return self._engine
 
     @torch.no_grad()
+    def forward(self, x, q_index=None, qp_scale=None):
+        """pWave.py:231-312 at inference: x_hat and the Laplace bit estimates of all subbands"""
+        if self.training:
+            raise NotImplementedError("training forward is not part of this build")
+        eng = self.engine()
+        qs = None if qp_scale is None else float(qp_scale)
+        x = x.contiguous().float()
+        r = eng.pwave_forward("coder", x, q_index, qs)
+        N, _, H, W = r["x_hat"].shape
+        vals = torch.cat([r["bits"], r["sq_err"]]).cpu()
+        bits, sq = vals[:N], float(vals[N])
+        t = lambda v: torch.tensor(v, dtype=torch.float32)
+        total = float(bits.sum())
+        return {"x_hat": r["x_hat"], "bits": {"bits_total": bits.float()}, "likelihoods": {"bits_total": bits.float()},
+                "subbands": r["subbands"], "bpp_total": t(total / (H * W * N)), "bits_total": t(total / N),
+                "mse": t(sq / x.numel())}
+
+    @torch.no_grad()
     def compress(self, x, sideinfo=None, file_name=None, q_index=None, skip_decoding=False, qp_scale=None):
         """pWave.py:380-464: code one image (Y, UV or RGB planes; sizes already padded) into `file_name`, return x_hat.
         With skip_decoding=False the LL subband is written in the sequential decoder's order."""

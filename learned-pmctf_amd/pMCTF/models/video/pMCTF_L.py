@@ -8,8 +8,9 @@ gfx950 kernels (pMCTF.hip.engine.HipEngine -> libpmctf_hip.so); the range coder 
 on host threads.  There is no CPU fallback: without a GPU and the built libraries the calls raise.
 
 Implemented: the write-stream encode branch (pMCTF_L.py:553-637) with skip_decoding True or False (real decoder:
-decompress_mv, decompress_one_stage), inverse_MCTF.  Not implemented (raise NotImplementedError): the estimate-only
-branch (output_path=None; broken in the reference itself), me_downsample > 1, training forward.
+decompress_mv, decompress_one_stage), inverse_MCTF, the estimate-mode forward (forward / forward_one_stage at
+inference).  Not implemented (raise NotImplementedError): the estimate-only branch of encode_one_stage
+(output_path=None; broken in the reference itself), me_downsample > 1, training-mode forward.
 """
 import os
 import os.path as osp
@@ -163,10 +164,48 @@ class pMCTF(nn.Module):
             out.append({"L_t": L_t, "H_t": {"x_hat": H_t}})
         return out
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("estimate-mode / training forward is outside the encode hot path of this build")
+    @torch.no_grad()
+    def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):
+        """Estimate-mode stage (pMCTF_L.py:332-379): the same networks as encode_one_stage with Laplace / factorized
+        bit estimates instead of range coding.  ref_frame / cur_frame are (N,1,H,W) planes (Y, or UV with the luma
+        motion passed as mv_hat).  Scalars come back as 0-dim float32 CPU tensors (one device read per call)."""
+        if me_downsample != 1:
+            raise NotImplementedError("me_downsample > 1")
+        if self.training:
+            raise NotImplementedError("training forward (noise quantisation, gradients) is not part of this build")
+        eng = self.engine()
+        dev = next(self.parameters()).device
+        ref, cur = ref_frame.to(dev).contiguous(), cur_frame.to(dev).contiguous()
+        r = eng.forward_one_stage(ref, cur, q_index, code_lt, dpb, None if mv_hat is None else mv_hat.contiguous(),
+                                  stage_idx)
+        acc = r["acc"]
+        keys = sorted(acc)
+        vals = torch.cat([acc[k].reshape(-1).sum().reshape(1) for k in keys]).cpu().tolist()     # the one sync
+        v = dict(zip(keys, vals))
+        N, _, H, W = ref.shape
+        pix = H * W
+        t = lambda x: None if x is None else torch.tensor(x, dtype=torch.float32)
+        has_mv = "bits_mv_y" in v
+        bpp_y = v["bits_mv_y"] / pix if has_mv else None
+        bpp_z = v["bits_mv_z"] / pix if has_mv else None
+        bpp_H = v["bits_H"] / (pix * N)
+        bpp = bpp_H + bpp_z + bpp_y if has_mv else bpp_H
+        nchw = lambda x: None if x is None else x.permute(0, 3, 1, 2)
+        ret = {"bpp_mv_y": t(bpp_y), "bpp_mv_z": t(bpp_z), "bpp_me": t(bpp_z + bpp_y) if has_mv else None,
+               "me_mse": t(v["sq_me"] / (pix * N)), "bpp": t(bpp), "bpp_H": t(bpp_H), "bit_H": t(v["bits_H"] / N),
+               "bit_ME": t((bpp_y + bpp_z) * pix) if has_mv else None, "mse_H": t(v["sq_H"] / (pix * N)),
+               "mv_hat": r["mv_hat"],
+               "dpb": {"mv_feature": nchw(r["ref_mv"]["mv_feature"]), "ref_mv_y": nchw(r["ref_mv"]["mv_y_hat"])},
+               "H_t": r["H_t"], "L_t": r["L_t"]}
+        if code_lt:
+            ret.update({"bpp_L": t(v["bits_L"] / (pix * N)), "bit_L": t(v["bits_L"] / N),
+                        "mse_L": t(v["sq_L"] / (pix * N)), "me_mse_inv": t(v["sq_me_inv"] / (pix * N))})
+        ret["bit"] = t(bpp * pix)
+        return ret
 
-    forward_one_stage = forward
+    def forward(self, ref_frame, cur_frame, q_index, code_lt, dpb, stage_idx=0):
+        """pMCTF_L.py:294-295"""
+        return self.forward_one_stage(ref_frame, cur_frame, q_index, code_lt, dpb, stage_idx=stage_idx)
 
     @torch.no_grad()
     def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,

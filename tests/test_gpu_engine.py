@@ -246,3 +246,44 @@ def test_full_size_1080p_properties(cuda):
     L_t, H_t, _, _ = net.forward_MCTF(fr[0][0], fr[1][0], e["mv_hat"])
     ref, cur = net.inverse_MCTF(L_t, H_t, e["mv_hat"])
     assert (ref - fr[0][0]).abs().max().item() < 1e-3 and (cur - fr[1][0]).abs().max().item() < 1e-3
+
+
+def test_estimate_mode_forward(setup):
+    """forward_one_stage (bit estimates, pMCTF_L.py:332-379): tensors bit-exact vs the oracle's PM-F32 restatement,
+    scalars to 1e-6 relative (f64 totals of per-element f32 values; the oracle sums in numpy order), and within 1e-4
+    relative of the real reference's fixtures."""
+    net, orc = setup
+    g = golden()
+    (Y0, C0), (Y1, C1) = frames(W, H, 2)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    ry = net.forward_one_stage(Y0.cuda(), Y1.cuda(), 3, True, dpb)
+    rc = net.forward_one_stage(C0.cuda(), C1.cuda(), 3, True, dpb, mv_hat=ry["mv_hat"])
+    rn = net(Y0.cuda(), Y1.cuda(), 12, False, ry["dpb"], stage_idx=0)
+    oy = orc.forward_one_stage(Y0, Y1, 3, True, dpb)
+    oc = orc.forward_one_stage(C0, C1, 3, True, dpb, mv_hat=oy["mv_hat"])
+    on = orc.forward_one_stage(Y0, Y1, 12, False, oy["dpb"], stage_idx=0)
+    n_scalars = 0
+    for tag, r, o in (("y", ry, oy), ("c", rc, oc), ("n", rn, on)):
+        for k, ov in o.items():
+            if k == "dpb":
+                for kk in ov:
+                    if ov[kk] is None:
+                        assert r["dpb"][kk] is None
+                    else:
+                        assert_same(r["dpb"][kk], ov[kk], f"{tag} dpb.{kk}")
+            elif ov is None:
+                assert r[k] is None, (tag, k)
+            elif isinstance(ov, torch.Tensor):
+                assert_same(r[k], ov, f"{tag} {k}")
+            else:
+                pv = float(r[k])
+                assert abs(pv - ov) <= 1e-6 * max(1.0, abs(ov)), (tag, k, pv, ov)
+                ref = float(g[f"est.{tag}.{k}"])
+                assert abs(pv - ref) <= 1e-4 * max(1.0, abs(ref)), (tag, k, pv, ref)
+                n_scalars += 1
+    assert n_scalars == 34
+    # the standalone coder's forward gives the L numbers of the luma pair
+    L_t = net.forward_MCTF(Y0.cuda(), Y1.cuda(), ry["mv_hat"])[0]
+    f = net.lp_coder(L_t, 3)
+    assert abs(float(f["bits_total"]) - oy["bit_L"]) <= 1e-6 * oy["bit_L"]
+    assert_same(f["x_hat"], oy["L_t"], "pWave.forward x_hat")

@@ -74,6 +74,10 @@ def test_product_path_has_no_cpu_fallback():
                              pic_width=128, pic_height=128, skip_decoding=True)
     with pytest.raises(NotImplementedError):
         net.encode_one_stage(fr[0], fr[1], False, {"mv_feature": None, "ref_mv_y": None}, output_path=None)
+    with pytest.raises(RuntimeError):       # estimate mode and the decoder need the GPU as well
+        net.eval().forward_one_stage(fr[0][0], fr[1][0], 3, True, {"mv_feature": None, "ref_mv_y": None})
+    with pytest.raises(RuntimeError):
+        net.lp_coder.compress(fr[0][0], [1, 1, 128, 128], "/tmp/x.bin", q_index=3)
 
 
 def test_product_tables_match_reference_kat():
