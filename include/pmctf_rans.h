@@ -22,9 +22,10 @@ extern "C" {
 typedef struct pmctf_rans_encoder pmctf_rans_encoder;
 typedef struct pmctf_rans_decoder pmctf_rans_decoder;
 
-/* RansEncoder(bool multiThread, int streamPart)                      py_rans.cpp:11-20
- * multi_thread is accepted for signature parity; coding is synchronous inside the call (callers
- * overlap whole streams on their own threads). */
+/* RansEncoder(bool multiThread, int streamPart)                      py_rans.cpp:11-20, rans.cpp:174-263
+ * multi_thread != 0: flush() returns at once and the stream is coded on a background thread (the stream_part parts in
+ * parallel); stream_size / get_encoded_stream / write_file / reset / encode_with_indexes wait for it.  The bytes are
+ * the same as with multi_thread == 0. */
 pmctf_rans_encoder *pmctf_rans_encoder_create(int multi_thread, int stream_part);
 void pmctf_rans_encoder_destroy(pmctf_rans_encoder *e);
 /* RansEncoder.reset()                                                 py_rans.cpp:121-125 */

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/pmctf_rans.h"
@@ -130,6 +131,43 @@ void flush_part(Part &p, const Entry *entries) {
 struct pmctf_rans_encoder {
     std::vector<Part> parts;
     std::vector<uint8_t> stream;  // assembled by flush()
+    bool multi_thread = false;    // flush() runs in the background (parts in parallel); readers join first
+    std::thread worker;
+    void join() { if (worker.joinable()) worker.join(); }
+    ~pmctf_rans_encoder() { join(); }
+
+    void assemble(bool parallel) {
+        const size_t np = parts.size();
+        if (parallel && np > 1) {
+            std::vector<std::thread> th;
+            for (size_t i = 1; i < np; ++i) th.emplace_back([this, i] { flush_part(parts[i], entries.data()); });
+            flush_part(parts[0], entries.data());
+            for (auto &t : th) t.join();
+        } else {
+            for (size_t i = 0; i < np; ++i) flush_part(parts[i], entries.data());
+        }
+        size_t total = 0, max_size = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const size_t sz = parts[i].stream.size();
+            total += sz;
+            if (i + 1 < np && sz > max_size) max_size = sz;
+        }
+        const size_t per_hdr = max_size > 65535 ? 4 : 2;
+        const size_t overhead = 1 + (np > 1 ? (np - 1) * per_hdr : 0);
+        stream.resize(total + overhead);
+        uint8_t *o = stream.data();
+        o[0] = (uint8_t)(((np - 1) << 4) + (per_hdr == 2 ? 1 : 0));
+        for (size_t i = 0; i + 1 < np; ++i) {
+            if (per_hdr == 2) { const uint16_t v = (uint16_t)parts[i].stream.size(); memcpy(o + 1 + 2 * i, &v, 2); }
+            else { const uint32_t v = (uint32_t)parts[i].stream.size(); memcpy(o + 1 + 4 * i, &v, 4); }
+        }
+        size_t off = overhead;
+        for (size_t i = 0; i < np; ++i) {
+            memcpy(o + off, parts[i].stream.data(), parts[i].stream.size());
+            off += parts[i].stream.size();
+        }
+    }
+
     std::vector<Entry> entries;   // flat interval table of every registered CDF table
     std::vector<Table> tables;
 
@@ -163,10 +201,13 @@ struct pmctf_rans_decoder {
 
 extern "C" {
 
-pmctf_rans_encoder *pmctf_rans_encoder_create(int /*multi_thread*/, int stream_part) {
+pmctf_rans_encoder *pmctf_rans_encoder_create(int multi_thread, int stream_part) {
     if (stream_part < 1 || stream_part > 16) return nullptr;
     auto *e = new (std::nothrow) pmctf_rans_encoder();
-    if (e) e->parts.resize((size_t)stream_part);
+    if (e) {
+        e->parts.resize((size_t)stream_part);
+        e->multi_thread = multi_thread != 0;
+    }
     return e;
 }
 
@@ -174,6 +215,7 @@ void pmctf_rans_encoder_destroy(pmctf_rans_encoder *e) { delete e; }
 
 int pmctf_rans_encoder_reset(pmctf_rans_encoder *e) {
     if (!e) return PMCTF_RANS_EINVAL;
+    e->join();
     for (auto &p : e->parts) p.steps.clear();
     return PMCTF_RANS_OK;
 }
@@ -185,6 +227,7 @@ int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t 
         return PMCTF_RANS_EINVAL;
     for (int r = 0; r < cdf_rows; ++r)
         if (cdf_sizes[r] < 2 || cdf_sizes[r] > cdf_cols) return PMCTF_RANS_EINVAL;
+    e->join();
     const uint32_t base = e->table_base(cdfs, cdf_rows, cdf_cols, cdf_sizes);
     if ((uint64_t)e->entries.size() >= kBypassFlag) return PMCTF_RANS_EINVAL;
     const int64_t nparts = (int64_t)e->parts.size();
@@ -207,34 +250,20 @@ int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t 
 
 int pmctf_rans_encoder_flush(pmctf_rans_encoder *e) {
     if (!e) return PMCTF_RANS_EINVAL;
-    size_t total = 0, max_size = 0;
-    const size_t np = e->parts.size();
-    for (size_t i = 0; i < np; ++i) {
-        flush_part(e->parts[i], e->entries.data());
-        const size_t sz = e->parts[i].stream.size();
-        total += sz;
-        if (i + 1 < np && sz > max_size) max_size = sz;
-    }
-    const size_t per_hdr = max_size > 65535 ? 4 : 2;
-    const size_t overhead = 1 + (np > 1 ? (np - 1) * per_hdr : 0);
-    e->stream.resize(total + overhead);
-    uint8_t *o = e->stream.data();
-    o[0] = (uint8_t)(((np - 1) << 4) + (per_hdr == 2 ? 1 : 0));
-    for (size_t i = 0; i + 1 < np; ++i) {
-        if (per_hdr == 2) { const uint16_t v = (uint16_t)e->parts[i].stream.size(); memcpy(o + 1 + 2 * i, &v, 2); }
-        else { const uint32_t v = (uint32_t)e->parts[i].stream.size(); memcpy(o + 1 + 4 * i, &v, 4); }
-    }
-    size_t off = overhead;
-    for (size_t i = 0; i < np; ++i) {
-        memcpy(o + off, e->parts[i].stream.data(), e->parts[i].stream.size());
-        off += e->parts[i].stream.size();
-    }
+    e->join();
+    if (e->multi_thread) e->worker = std::thread([e] { e->assemble(true); });
+    else e->assemble(false);
     return PMCTF_RANS_OK;
 }
 
-int64_t pmctf_rans_encoder_stream_size(const pmctf_rans_encoder *e) { return e ? (int64_t)e->stream.size() : PMCTF_RANS_EINVAL; }
+int64_t pmctf_rans_encoder_stream_size(const pmctf_rans_encoder *e) {
+    if (!e) return PMCTF_RANS_EINVAL;
+    const_cast<pmctf_rans_encoder *>(e)->join();
+    return (int64_t)e->stream.size();
+}
 
 int pmctf_rans_encoder_get_encoded_stream(const pmctf_rans_encoder *e, uint8_t *out, int64_t capacity) {
+    if (e) const_cast<pmctf_rans_encoder *>(e)->join();
     if (!e || !out || capacity < (int64_t)e->stream.size()) return PMCTF_RANS_EINVAL;
     memcpy(out, e->stream.data(), e->stream.size());
     return PMCTF_RANS_OK;
@@ -243,6 +272,7 @@ int pmctf_rans_encoder_get_encoded_stream(const pmctf_rans_encoder *e, uint8_t *
 int64_t pmctf_rans_encoder_write_file(const pmctf_rans_encoder *e, const uint8_t *header, int64_t header_len,
                                       const char *path) {
     if (!e || !path || header_len < 0 || (header_len > 0 && !header)) return PMCTF_RANS_EINVAL;
+    const_cast<pmctf_rans_encoder *>(e)->join();
     FILE *f = fopen(path, "wb");
     if (!f) return PMCTF_RANS_EIO;
     bool ok = true;

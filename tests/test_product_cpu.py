@@ -100,7 +100,7 @@ def test_product_tables_match_reference_kat():
     assert g.decode_stream(sc, torch.float32, "cpu").int().tolist() == sym.tolist()
 
 
-@pytest.mark.parametrize("parts", [1, 2, 3])
+@pytest.mark.parametrize("parts", [1, 2, 3, 16])
 def test_host_range_coder_matches_oracle_and_round_trips(parts):
     from pmctf_oracle import clib, entropy
     from pMCTF.entropy_models.entropy_models import EntropyCoder
@@ -127,9 +127,19 @@ def test_host_range_coder_matches_oracle_and_round_trips(parts):
             o.encode_with_indexes(sym[a:b], idx[a:b], cdf, ln, off)
         o.flush()
         assert o.get_encoded_stream().tobytes() == s
-        ec.set_stream(s)
-        out = ec.decode_stream(torch.from_numpy(idx), cdf, ln, off).numpy().astype(np.int16)
-        assert np.array_equal(out, sym)
+    # every part count decodes (one decode_stream per push, as the pushes were split; py_rans.cpp:29-52,174-196)
+    ec.set_stream(s)
+    out = np.concatenate([ec.decode_stream(torch.from_numpy(idx[a:b]), cdf, ln, off).numpy().astype(np.int16)
+                          for a, b in ((0, n // 3), (n // 3, n))])
+    assert np.array_equal(out, sym)
+    # the threaded encoder (flush in the background, parts in parallel) writes the same bytes
+    et = EntropyCoder(True, parts)
+    for _ in range(2):                              # twice: reset() after a background flush
+        et.reset()
+        for a, b in ((0, n // 3), (n // 3, n)):
+            et.encode_with_indexes(sym[a:b], idx[a:b], cdf, ln, off)
+        et.flush()
+        assert et.get_encoded_stream() == s
     with tempfile.TemporaryDirectory() as td:
         from pMCTF.hip import lib
         path = os.path.join(td, "s.bin")
@@ -216,3 +226,21 @@ def test_gop_sharding_world_size_2_gloo():
     for _, _, bits, psnr in res:
         assert bits == expect_bits
         assert abs(psnr[3][2] - 33.2) < 1e-12
+
+
+def test_bitstream_inspector_reads_reference_files():
+    """tools/inspect_bitstream.py parses files written by the real reference (fixtures) with the standard library only"""
+    import subprocess, sys
+    from helpers import golden
+    g = golden()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for k in ("dec.file.1.bin", "dec.file.1_mv.bin", "dec.file.1_C_main.bin", "dec.file.0_main.bin"):
+            p = os.path.join(td, k[len("dec.file."):])
+            open(p, "wb").write(g[k].tobytes())
+            paths.append(p)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "inspect_bitstream.py")] + paths,
+                             capture_output=True, text=True, check=True).stdout
+    assert "image file: 128x128 (Y)" in out and "image file: 64x64 (UV)" in out and "motion file: mv_y_q_index 0" in out
+    assert out.count("1 part(s)") == 4 and "(!)" not in out
