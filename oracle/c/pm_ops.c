@@ -258,8 +258,8 @@ void pm_avgpool2(const float *x, float *y, int NC, int H, int W) {
  * i1 = i0 + (i0 < size-1).  t(row) = fmaf(v[i0], l0x, v[i1]*l1x) ; out = fmaf(t(r0), l0y, t(r1)*l1y)
  * (ATen's CPU kernel evaluates exactly this on planes of >= ~2^15 outputs; on smaller planes it
  * takes another path that differs in the last bit — see tests/test_oracle_ops.py). */
-static inline void pm_up2_coef(int d, int size, int *i0, int *i1, float *l0, float *l1) {
-    float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+static inline void pm_up_coef(int d, int size, float rf, int *i0, int *i1, float *l0, float *l1) {
+    float src = rf * ((float)d + 0.5f) - 0.5f;
     if (src < 0.0f) src = 0.0f;
     int a = (int)floorf(src);
     if (a > size - 1) a = size - 1;
@@ -271,39 +271,44 @@ static inline void pm_up2_coef(int d, int size, int *i0, int *i1, float *l0, flo
     *l1 = lam;
     *l0 = 1.0f - lam;
 }
-void pm_bilinear_up2(const float *x, float *y, int NC, int H, int W) {
-    const int Ho = 2 * H, Wo = 2 * W;
+/* general power-of-two factor f (me_downsample 2/4/8, pMCTF_L.py:475-476): src = (dst+0.5)/f - 0.5, same formula */
+void pm_bilinear_up(const float *x, float *y, int NC, int H, int W, int f) {
+    const int Ho = f * H, Wo = f * W;
+    const float rf = 1.0f / (float)f;
     for (long job = 0; job < (long)NC * Ho; ++job) {
         const int oy = (int)(job % Ho);
         const long nc = job / Ho;
         int y0, y1; float ly0, ly1;
-        pm_up2_coef(oy, H, &y0, &y1, &ly0, &ly1);
+        pm_up_coef(oy, H, rf, &y0, &y1, &ly0, &ly1);
         const float *r0 = x + (nc * H + y0) * W, *r1 = x + (nc * H + y1) * W;
         float *o = y + (nc * Ho + oy) * Wo;
         for (int ox = 0; ox < Wo; ++ox) {
             int x0, x1; float lx0, lx1;
-            pm_up2_coef(ox, W, &x0, &x1, &lx0, &lx1);
+            pm_up_coef(ox, W, rf, &x0, &x1, &lx0, &lx1);
             const float t0 = fmaf(r0[x0], lx0, r0[x1] * lx1);
             const float t1 = fmaf(r1[x0], lx0, r1[x1] * lx1);
             o[ox] = fmaf(t0, ly0, t1 * ly1);
         }
     }
 }
+void pm_bilinear_up2(const float *x, float *y, int NC, int H, int W) { pm_bilinear_up(x, y, NC, H, W, 2); }
 
 /* bilinear /2 downsampling, align_corners=False (video_net.py:66-71):
  * src = 2*dst+0.5 -> i0 = 2dst, weights 0.5/0.5 in both directions.
  * t(row) = v0*0.5 + v1*0.5 ; out = t0*0.5 + t1*0.5 */
-void pm_bilinear_down2(const float *x, float *y, int NC, int H, int W) {
-    const int Ho = H / 2, Wo = W / 2;
+/* general even factor f (me_downsample, pMCTF_L.py:456-458): src = f*dst + f/2 - 0.5 -> the two centre samples */
+void pm_bilinear_down(const float *x, float *y, int NC, int H, int W, int f) {
+    const int Ho = H / f, Wo = W / f, c = f / 2 - 1;
     for (long job = 0; job < (long)NC * Ho; ++job) {
         const int oy = (int)(job % Ho);
         const long nc = job / Ho;
-        const float *r0 = x + (nc * H + 2 * oy) * W, *r1 = r0 + W;
+        const float *r0 = x + (nc * H + f * oy + c) * W, *r1 = r0 + W;
         float *o = y + (nc * Ho + oy) * Wo;
         for (int ox = 0; ox < Wo; ++ox) {
-            const float t0 = r0[2 * ox] * 0.5f + r0[2 * ox + 1] * 0.5f;
-            const float t1 = r1[2 * ox] * 0.5f + r1[2 * ox + 1] * 0.5f;
+            const float t0 = r0[f * ox + c] * 0.5f + r0[f * ox + c + 1] * 0.5f;
+            const float t1 = r1[f * ox + c] * 0.5f + r1[f * ox + c + 1] * 0.5f;
             o[ox] = t0 * 0.5f + t1 * 0.5f;
         }
     }
 }
+void pm_bilinear_down2(const float *x, float *y, int NC, int H, int W) { pm_bilinear_down(x, y, NC, H, W, 2); }

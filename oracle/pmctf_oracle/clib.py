@@ -39,6 +39,8 @@ def lib():
     L.pm_flow_warp.argtypes = [f32p, f32p, f32p, f32p, f32p] + [C.c_int] * 5
     for n in ("pm_avgpool2", "pm_bilinear_up2", "pm_bilinear_down2"):
         getattr(L, n).argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
+    for n in ("pm_bilinear_up", "pm_bilinear_down"):
+        getattr(L, n).argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.pm_rans_enc_new.restype = C.c_void_p
     L.pm_rans_enc_free.argtypes = [C.c_void_p]
     L.pm_rans_enc_reset.argtypes = [C.c_void_p]
@@ -131,20 +133,30 @@ def avgpool2(x):
     return y
 
 
-def bilinear_up2(x):
+def bilinear_up(x, f=2):
     x = _c(x)
     N, Cc, H, W = x.shape
-    y = np.empty((N, Cc, 2 * H, 2 * W), np.float32)
-    lib().pm_bilinear_up2(x, y, N * Cc, H, W)
+    assert f in (2, 4, 8)
+    y = np.empty((N, Cc, f * H, f * W), np.float32)
+    lib().pm_bilinear_up(x, y, N * Cc, H, W, f)
     return y
+
+
+def bilinear_down(x, f=2):
+    x = _c(x)
+    N, Cc, H, W = x.shape
+    assert f in (2, 4, 8) and H >= f and W >= f
+    y = np.empty((N, Cc, H // f, W // f), np.float32)
+    lib().pm_bilinear_down(x, y, N * Cc, H, W, f)
+    return y
+
+
+def bilinear_up2(x):
+    return bilinear_up(x, 2)
 
 
 def bilinear_down2(x):
-    x = _c(x)
-    N, Cc, H, W = x.shape
-    y = np.empty((N, Cc, H // 2, W // 2), np.float32)
-    lib().pm_bilinear_down2(x, y, N * Cc, H, W)
-    return y
+    return bilinear_down(x, 2)
 
 
 def pmf_to_quantized_cdf(pmf, precision=16):

@@ -53,11 +53,11 @@ class TorchK:
     def avg_pool2(self, x):
         return F.avg_pool2d(x, kernel_size=2, stride=2)
 
-    def bilinear_up2(self, x):
-        return F.interpolate(x, (x.size(2) * 2, x.size(3) * 2), mode="bilinear", align_corners=False)
+    def bilinear_up2(self, x, f=2):
+        return F.interpolate(x, (x.size(2) * f, x.size(3) * f), mode="bilinear", align_corners=False)
 
-    def bilinear_down2(self, x):
-        return F.interpolate(x, (x.size(2) // 2, x.size(3) // 2), mode="bilinear", align_corners=False)
+    def bilinear_down2(self, x, f=2):
+        return F.interpolate(x, (x.size(2) // f, x.size(3) // f), mode="bilinear", align_corners=False)
 
     def build_indexes(self, tables, scales):
         return tables.build_indexes_torch(scales)
@@ -122,11 +122,11 @@ class CdefK(TorchK):
     def avg_pool2(self, x):
         return _t(clib.avgpool2(x.numpy()))
 
-    def bilinear_up2(self, x):
-        return _t(clib.bilinear_up2(x.numpy()))
+    def bilinear_up2(self, x, f=2):
+        return _t(clib.bilinear_up(x.numpy(), f))
 
-    def bilinear_down2(self, x):
-        return _t(clib.bilinear_down2(x.numpy()))
+    def bilinear_down2(self, x, f=2):
+        return _t(clib.bilinear_down(x.numpy(), f))
 
     def build_indexes(self, tables, scales):
         return tables.build_indexes_cdef(scales)

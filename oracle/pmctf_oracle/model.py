@@ -354,11 +354,14 @@ class Oracle:
         dec, _ = get_rounded_q(dec.numpy())
         return enc, dec
 
-    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0):
+    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0, me_downsample=1):
         s = min(self.num_me_stages - 1, stage_idx)
         q_enc, q_dec = self.get_mv_y_q(q_index, s)
         mv_x = cur_y.tile((1, 3, 1, 1)) / 255
         mv_ref = ref_y.tile((1, 3, 1, 1)) / 255
+        if me_downsample > 1:                                   # pMCTF_L.py:456-458
+            mv_x = self.K.bilinear_down2(mv_x, me_downsample)
+            mv_ref = self.K.bilinear_down2(mv_ref, me_downsample)
         est_mv = self.spynet(mv_x, mv_ref)
         self.tap("est_mv", est_mv)
         mv_y = self.mv_enc(s, est_mv, dpb["mv_feature"], q_enc)
@@ -370,6 +373,8 @@ class Oracle:
         self.tap("mv_params", mv_params)
         qw, sw, mv_y_hat = self.compress_four_part_prior(s, mv_y, mv_params)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        if me_downsample > 1:                                   # :475-476
+            mv_hat = self.K.bilinear_up2(mv_hat, me_downsample) * me_downsample
         self.new_stream()
         be = self.bit_est[s]
         idx = be.build_indexes(mv_z_hat.size())
@@ -626,10 +631,9 @@ class Oracle:
     # ------------------------------------------------------------------ a1: encode_one_stage write branch, pMCTF_L.py:553-637
     def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
                          psize=128, skip_decoding=True, stage_idx=0, q_index=0, me_downsample=1):
-        assert me_downsample == 1
         ref_y, ref_c = ref_frame
         cur_y, cur_c = cur_frame
-        mv = self.compress_mv(ref_y, cur_y, dpb, stage_idx=stage_idx, q_index=q_index)
+        mv = self.compress_mv(ref_y, cur_y, dpb, stage_idx=stage_idx, q_index=q_index, me_downsample=me_downsample)
         files = {"mv": encode_p_bytes(mv["bit_stream"], 0)}
         luma = self.compress_one_stage(ref_y, cur_y, code_lt, mv["mv_hat"], False, [1, 1, pic_height, pic_width],
                                        stage_idx, q_index, skip_decoding)
@@ -651,7 +655,8 @@ class Oracle:
         bits = {k: len(v) * 8.0 for k, v in files.items()}
         mv_hat_out, mv_feature_out = mv["mv_hat"], mv["mv_feature"]
         if not skip_decoding:        # pMCTF_L.py:594-612: return what the decoder reconstructs from the files
-            dec = self.decode_one_stage(files, code_lt, dpb, pic_height, pic_width, psize, stage_idx, q_index)
+            dec = self.decode_one_stage(files, code_lt, dpb, pic_height, pic_width, psize, stage_idx, q_index,
+                                        me_downsample)
             mv_hat_out, mv_feature_out = dec["mv_hat"], dec["mv_feature"]
             luma = dict(luma, H_t_hat=dec["H_t"], L_t_hat=dec.get("L_t"))
             chroma = dict(chroma, H_t_hat=dec["H_tc"], L_t_hat=dec.get("L_tc"))
@@ -825,8 +830,8 @@ class _DecoderMixin:
             so_far = cur if so_far is None else so_far + cur
         return so_far * quant_step
 
-    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0):
-        """pMCTF.decompress_mv, pMCTF_L.py:497-523"""
+    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
+        """pMCTF.decompress_mv, pMCTF_L.py:497-523 (height/width: size of the plane motion was estimated on)"""
         s = min(self.num_me_stages - 1, stage_idx)
         _, q_dec = self.get_mv_y_q(q_index, s)
         self.ec = entropy.EntropyCoder()
@@ -838,14 +843,19 @@ class _DecoderMixin:
         mv_params = self.mv_prior_param_decoder(z_hat, dpb, s)
         mv_y_hat = self.decompress_four_part_prior(s, mv_params)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        if me_downsample > 1:
+            mv_hat = self.K.bilinear_up2(mv_hat, me_downsample) * me_downsample
         return {"mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat}
 
-    def decode_one_stage(self, files, code_lt, dpb, pic_height, pic_width, psize=128, stage_idx=0, q_index=0):
-        """decode branch of encode_one_stage (pMCTF_L.py:594-612): files = the dict written by the encoder"""
+    def decode_one_stage(self, files, code_lt, dpb, pic_height, pic_width, psize=128, stage_idx=0, q_index=0,
+                         me_downsample=1):
+        """decode branch of encode_one_stage (pMCTF_L.py:594-612): files = the dict written by the encoder.
+        (With me_downsample > 1 the reference's own branch passes the full-resolution size and no factor to
+        decompress_mv, :597-602, which cannot decode; here the motion stream is decoded at the size it was coded at.)"""
         _, string = decode_p_bytes(files["mv"])
         ph = (pic_height + psize - 1) // psize * psize
         pw = (pic_width + psize - 1) // psize * psize
-        mv = self.decompress_mv(string, ph, pw, dpb, stage_idx, q_index)
+        mv = self.decompress_mv(string, ph // me_downsample, pw // me_downsample, dpb, stage_idx, q_index, me_downsample)
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
         out = {"mv_hat": mv["mv_hat"], "mv_feature": mv["mv_feature"], "mv_y_hat": mv["mv_y_hat"],
                "H_t": self.pwave_decompress("hp_coder", files["H"], psize, q_index, qp_scale),
@@ -945,13 +955,16 @@ class _EstimateMixin:
         """MVCoderQuad.forward_four_part_prior(write=False): (y_q, y_hat, scales_hat), four_part_prior.py:89-195"""
         return self.compress_four_part_prior(s, y, common_params, full=True)
 
-    def compute_and_code_motion(self, ref_frame, cur_frame, q_index, dpb, stage_idx=0):
-        """pMCTF_L.py:244-292 at inference (me_downsample=1)"""
+    def compute_and_code_motion(self, ref_frame, cur_frame, q_index, dpb, stage_idx=0, me_downsample=1):
+        """pMCTF_L.py:244-292 at inference"""
         s = min(self.num_me_stages - 1, stage_idx)
         q_enc = get_curr_q(self.sd[f"mv_y_q_scale_enc.{s}"], q_index)          # not rounded here (inference=False)
         q_dec = get_curr_q(self.sd[f"mv_y_q_scale_dec.{s}"], q_index)
         mv_cur = cur_frame[0, :, :, :].tile((1, 3, 1, 1)) / 255
         mv_ref = ref_frame[0, :, :, :].tile((1, 3, 1, 1)) / 255
+        if me_downsample > 1:
+            mv_cur = self.K.bilinear_down2(mv_cur, me_downsample)
+            mv_ref = self.K.bilinear_down2(mv_ref, me_downsample)
         est_mv = self.spynet(mv_cur, mv_ref)
         mv_y = self.mv_enc(s, est_mv, dpb["mv_feature"], q_enc)
         mv_z = self.mv_hyper_enc(s, mv_y)
@@ -959,6 +972,8 @@ class _EstimateMixin:
         mv_params = self.mv_prior_param_decoder(mv_z_hat, dpb, s)
         mv_y_q, mv_y_hat, mv_scales_hat = self.forward_four_part_prior(s, mv_y, mv_params)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        if me_downsample > 1:
+            mv_hat = self.K.bilinear_up2(mv_hat, me_downsample) * me_downsample
         bits_y = self.K.laplace_bits(mv_y_q, mv_scales_hat)
         bits_z = self.K.z_bits(mv_z_hat, self.bitparm_params(s))
         pixel_num = ref_frame.size(2) * ref_frame.size(3)
@@ -970,14 +985,15 @@ class _EstimateMixin:
             bpp_z = self.K.total(bits_z) / pixel_num
         return mv_hat, {"mv_feature": mv_feature, "mv_y_hat": mv_y_hat}, bpp_y, bpp_z
 
-    def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0):
+    def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):
         """pMCTF_L.py:332-379"""
         if mv_hat is not None:
             bpp_y = bpp_z = None
             ref_mv = {"mv_feature": None, "mv_y_hat": None}
             mv_hat = self.K.bilinear_down2(mv_hat) / 2
         else:
-            mv_hat, ref_mv, bpp_y, bpp_z = self.compute_and_code_motion(ref_frame, cur_frame, q_index, dpb, stage_idx)
+            mv_hat, ref_mv, bpp_y, bpp_z = self.compute_and_code_motion(ref_frame, cur_frame, q_index, dpb, stage_idx,
+                                                                        me_downsample)
         L_t, H_t, pred, inv = self.forward_MCTF(ref_frame, cur_frame, mv_hat, stage_idx)
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
         res_H = self.pwave_forward("hp_coder", H_t, q_index, qp_scale)

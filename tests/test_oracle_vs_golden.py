@@ -106,3 +106,29 @@ def test_estimate_mode_forward(sd, backend, rtol, ttol):
                 assert abs(v - ref) <= rtol * max(1.0, abs(ref)), (key, v, ref)
                 checked += 1
     assert checked == sum(1 for k in g.files if k.startswith("est.") and g[k].shape == ()) == 34
+
+
+@pytest.mark.parametrize("backend,ttol", [("torch", 1e-4), ("cdef", 2e-3)])
+def test_half_resolution_motion(sd, backend, ttol):
+    """me_downsample=2 (pMCTF_L.py:456-458,475-476,516-517): encode, standalone decompress_mv and the estimate-mode
+    forward against the real reference's files / tensors."""
+    from pmctf_oracle.model import Oracle, decode_p_bytes
+    g = golden()
+    o = Oracle(sd, 1, backend)
+    fr = frames(W, H, 2)
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with torch.no_grad():
+        r = o.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=W, pic_height=H, q_index=3, me_downsample=2)
+        names = {"mv": "1_mv.bin", "H": "1.bin", "Hc": "1_C_main.bin"}
+        for k, n in names.items():
+            assert r["files"][k] == g[f"ds2.file.{n}"].tobytes(), n
+        for k in ("H_t", "H_tc", "mv_hat"):
+            assert _close(r[k], g[f"ds2.{k}"], ttol), k
+        _, string = decode_p_bytes(r["files"]["mv"])
+        d = o.decompress_mv(string, H // 2, W // 2, dpb, 0, 3, me_downsample=2)
+        assert _close(d["mv_hat"], g["ds2.dec.mv_hat"], ttol) and _close(d["mv_feature"], g["ds2.dec.mv_feature"], ttol)
+        e = o.forward_one_stage(fr[0][0], fr[1][0], 3, False, dpb, me_downsample=2)
+        for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse"):
+            ref = float(g[f"ds2.est.{k}"])
+            assert abs(e[k] - ref) <= 2e-5 * max(1.0, abs(ref)), (k, e[k], ref)
+        assert _close(e["mv_hat"], g["ds2.est.mv_hat"], ttol) and _close(e["H_t"], g["ds2.est.H_t"], ttol)

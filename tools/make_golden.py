@@ -212,6 +212,25 @@ def main():
                 elif v is not None:
                     out[f"est.{tag}.{k}"] = np.asarray(v.detach().numpy()).copy()
 
+        # ---- motion estimated and coded at half resolution (me_downsample=2, pMCTF_L.py:456-458,475-476,516-517) ------
+        with tempfile.TemporaryDirectory() as td:
+            from pMCTF.utils.stream_helper import decode_p
+            dpb = {"mv_feature": None, "ref_mv_y": None}
+            r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
+                                     pic_height=H, pic_width=W, stage_idx=0, code_lt=False, psize=128,
+                                     skip_decoding=True, dpb=dpb, q_index=3, me_downsample=2)
+            for name in sorted(os.listdir(td)):
+                out[f"ds2.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
+            for k in ("H_t", "H_tc", "mv_hat"):
+                out[f"ds2.{k}"] = r[k].numpy().copy()
+            _, string = decode_p(os.path.join(td, "1_mv.bin"))
+            d = net.decompress_mv(string, torch.float32, H // 2, W // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
+            out["ds2.dec.mv_hat"] = d["mv_hat"].numpy().copy()
+            out["ds2.dec.mv_feature"] = d["mv_feature"].numpy().copy()
+            e = net.forward_one_stage(Y0, Y1, 3, False, dpb, me_downsample=2)
+            for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse", "mv_hat", "H_t"):
+                out[f"ds2.est.{k}"] = np.asarray(e[k].detach().numpy()).copy()
+
     path = os.path.join(args.out, f"reference_{W}x{H}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}.meta.json"), "w"), indent=1)
