@@ -113,6 +113,10 @@ int pmctf_avgpool2_f32(const float *x, float *y, int NC, int H, int W, void *str
 int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, int W, float scale, void *stream);
 /* F.interpolate bilinear /2, align_corners=False, result divided by `div` (video_net.py:66-71; pMCTF_L.py:317,401) */
 int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H, int W, float div, void *stream);
+/* the same two for factor 2, 4 or 8: bilinearupsacling / bilineardownsacling(x, factor) of the me_downsample paths
+ * (video_net.py:58-71; pMCTF_L.py:255-257,274-275,456-458,475-476,516-517) */
+int pmctf_bilinear_up_f32(const float *x, float *y, int NC, int H, int W, int factor, float scale, void *stream);
+int pmctf_bilinear_down_f32(const float *x, float *y, int NC, int H, int W, int factor, float div, void *stream);
 
 /* ---- elementwise / layout family -------------------------------------------------------------
  * One strided kernel covers the reference's glue tensor ops (torch add/sub/mul/div, slicing, cat,

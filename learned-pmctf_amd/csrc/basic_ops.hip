@@ -409,8 +409,8 @@ __global__ void avgpool2_kernel(const float *__restrict__ x, float *y, int NC, i
     }
 }
 
-__device__ __forceinline__ void up2_coef(int d, int size, int &i0, int &i1, float &l0, float &l1) {
-    float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+__device__ __forceinline__ void up_coef(int d, int size, float rf, int &i0, int &i1, float &l0, float &l1) {
+    float src = rf * ((float)d + 0.5f) - 0.5f;
     if (src < 0.0f) src = 0.0f;
     int a = (int)__builtin_floorf(src);
     if (a > size - 1) a = size - 1;
@@ -423,8 +423,10 @@ __device__ __forceinline__ void up2_coef(int d, int size, int &i0, int &i1, floa
     l0 = 1.0f - lam;
 }
 
-__global__ void bilinear_up2_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float scale) {
-    const int Ho = 2 * H, Wo = 2 * W;
+// bilinear upsampling by a power-of-two factor f, align_corners=False: src = (dst + 0.5)/f - 0.5
+__global__ void bilinear_up_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, int f, float scale) {
+    const int Ho = f * H, Wo = f * W;
+    const float rf = 1.0f / (float)f;
     const long total = (long)NC * Ho * Wo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(idx % Wo);
@@ -433,8 +435,8 @@ __global__ void bilinear_up2_kernel(const float *__restrict__ x, float *y, int N
         const long nc = p / Ho;
         int x0, x1, y0, y1;
         float lx0, lx1, ly0, ly1;
-        up2_coef(ox, W, x0, x1, lx0, lx1);
-        up2_coef(oy, H, y0, y1, ly0, ly1);
+        up_coef(ox, W, rf, x0, x1, lx0, lx1);
+        up_coef(oy, H, rf, y0, y1, ly0, ly1);
         const float *r0 = x + (nc * H + y0) * W, *r1 = x + (nc * H + y1) * W;
         const float t0 = __builtin_fmaf(r0[x0], lx0, r0[x1] * lx1);
         const float t1 = __builtin_fmaf(r1[x0], lx0, r1[x1] * lx1);
@@ -442,15 +444,16 @@ __global__ void bilinear_up2_kernel(const float *__restrict__ x, float *y, int N
     }
 }
 
-__global__ void bilinear_down2_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float div) {
-    const int Ho = H / 2, Wo = W / 2;
+// bilinear downsampling by an even factor f, align_corners=False: src = f*dst + f/2 - 0.5 -> the two centre samples
+__global__ void bilinear_down_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, int f, float div) {
+    const int Ho = H / f, Wo = W / f, c = f / 2 - 1;
     const long total = (long)NC * Ho * Wo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(idx % Wo);
         long p = idx / Wo;
         const int oy = (int)(p % Ho);
         const long nc = p / Ho;
-        const float *r0 = x + (nc * H + 2 * oy) * W + 2 * ox;
+        const float *r0 = x + (nc * H + f * oy + c) * W + f * ox + c;
         const float *r1 = r0 + W;
         const float t0 = r0[0] * 0.5f + r0[1] * 0.5f;
         const float t1 = r1[0] * 0.5f + r1[1] * 0.5f;
@@ -578,18 +581,29 @@ extern "C" int pmctf_avgpool2_f32(const float *x, float *y, int NC, int H, int W
     return launch_ok();
 }
 
-extern "C" int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, int W, float scale, void *stream) {
-    if (!x || !y || NC <= 0 || H <= 0 || W <= 0) return PMCTF_EINVAL;
-    unsigned g = nblocks((long)NC * H * W * 4);
+extern "C" int pmctf_bilinear_up_f32(const float *x, float *y, int NC, int H, int W, int factor, float scale,
+                                     void *stream) {
+    if (!x || !y || NC <= 0 || H <= 0 || W <= 0 || (factor != 2 && factor != 4 && factor != 8)) return PMCTF_EINVAL;
+    unsigned g = nblocks((long)NC * H * W * factor * factor);
     if (g > 16384) g = 16384;
-    PM_LAUNCH(bilinear_up2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, scale);
+    PM_LAUNCH(bilinear_up_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, factor, scale);
     return launch_ok();
 }
 
-extern "C" int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H, int W, float div, void *stream) {
-    if (!x || !y || NC <= 0 || H < 2 || W < 2) return PMCTF_EINVAL;
-    unsigned g = nblocks((long)NC * (H / 2) * (W / 2));
+extern "C" int pmctf_bilinear_down_f32(const float *x, float *y, int NC, int H, int W, int factor, float div,
+                                       void *stream) {
+    if (!x || !y || NC <= 0 || (factor != 2 && factor != 4 && factor != 8) || H < factor || W < factor)
+        return PMCTF_EINVAL;
+    unsigned g = nblocks((long)NC * (H / factor) * (W / factor));
     if (g > 16384) g = 16384;
-    PM_LAUNCH(bilinear_down2_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, div);
+    PM_LAUNCH(bilinear_down_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, factor, div);
     return launch_ok();
+}
+
+extern "C" int pmctf_bilinear_up2_f32(const float *x, float *y, int NC, int H, int W, float scale, void *stream) {
+    return pmctf_bilinear_up_f32(x, y, NC, H, W, 2, scale, stream);
+}
+
+extern "C" int pmctf_bilinear_down2_f32(const float *x, float *y, int NC, int H, int W, float div, void *stream) {
+    return pmctf_bilinear_down_f32(x, y, NC, H, W, 2, div, stream);
 }

@@ -239,9 +239,12 @@ class HipEngine:
         return ref, cur
 
     # ------------------------------------------------------------------ a3 SpyNet (video_net.py:93-121)
-    def spynet(self, cur_y, ref_y, levels=6):
+    def spynet(self, cur_y, ref_y, levels=6, me_downsample=1):
         im1 = [ew(EW_DIVS, cur_y, alpha=255.0)]
         im2 = [ew(EW_DIVS, ref_y, alpha=255.0)]
+        if me_downsample > 1:       # the planes are scaled to 0..1 first, then reduced (pMCTF_L.py:452-458)
+            im1 = [ops.bilinear_down2(im1[0], 1.0, me_downsample)]
+            im2 = [ops.bilinear_down2(im2[0], 1.0, me_downsample)]
         for l in range(levels - 1):
             im1.append(ops.avgpool2(im1[l]))
             im2.append(ops.avgpool2(im2[l]))
@@ -386,12 +389,12 @@ class HipEngine:
             self._bitparm[s] = c
         return c
 
-    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0, estimate=False):
+    def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0, estimate=False, me_downsample=1):
         """estimate=True: compute_and_code_motion (pMCTF_L.py:244-292): same networks, unrounded quantisation steps,
         bit estimates (two device float64: y, z) instead of a symbol stream"""
         s = min(self.num_me_stages - 1, stage_idx)
         q_enc, q_dec = self.get_mv_y_q(q_index, s, inference=not estimate)
-        est_mv = self.spynet(cur_y, ref_y)
+        est_mv = self.spynet(cur_y, ref_y, me_downsample=me_downsample)
         mv_y = self.mv_enc(s, est_mv, self.to_nhwc_input(dpb["mv_feature"]), q_enc)
         mv_z = self.mv_hyper_enc(s, mv_y)
         _, hy, wy, _ = mv_y.shape
@@ -419,6 +422,8 @@ class HipEngine:
                                      stream.take(16 * hy * wy, "gauss"), t, self.lmin, self.lstep)
         mv_y_hat = ops.mv_dequant(so_far, common)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        if me_downsample > 1:       # pMCTF_L.py:274-275,475-476
+            mv_hat = ops.bilinear_up2(mv_hat, float(me_downsample), me_downsample)
         out = {"stream": stream, "mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat,
                "est_mv": est_mv, "mv_y": mv_y, "z_hat": z_hat, "common": common}
         if estimate:
@@ -658,7 +663,7 @@ class HipEngine:
         return x_hat, stream
 
     # ------------------------------------------------------------------ estimate-mode stage (pMCTF_L.py:332-379)
-    def forward_one_stage(self, ref, cur, q_index, code_lt, dpb, mv_hat=None, stage_idx=0):
+    def forward_one_stage(self, ref, cur, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):
         """Returns tensors plus a dict `acc` of device float64 accumulators; the caller turns them into the
         reference's bpp / mse scalars with ONE synchronising read."""
         acc = {}
@@ -666,7 +671,8 @@ class HipEngine:
             mv_hat = ops.bilinear_down2(mv_hat, 2.0)
             ref_mv = {"mv_feature": None, "mv_y_hat": None}
         else:
-            mv = self.compress_mv(ref[0:1], cur[0:1], dpb, stage_idx=stage_idx, q_index=q_index, estimate=True)
+            mv = self.compress_mv(ref[0:1], cur[0:1], dpb, stage_idx=stage_idx, q_index=q_index, estimate=True,
+                                  me_downsample=me_downsample)
             mv_hat = mv["mv_hat"]
             ref_mv = mv
             acc["bits_mv_y"], acc["bits_mv_z"] = mv["bits_y"], mv["bits_z"]
@@ -863,8 +869,8 @@ class HipEngine:
             rec_ll = out
         return self.post_process(coder, out, 256.0, 256.0)
 
-    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0):
-        """pMCTF.decompress_mv (pMCTF_L.py:497-523)"""
+    def decompress_mv(self, string, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
+        """pMCTF.decompress_mv (pMCTF_L.py:497-523); height/width: size of the plane motion was estimated on"""
         s = min(self.num_me_stages - 1, stage_idx)
         _, q_dec = self.get_mv_y_q(q_index, s)
         dec = HostDecoder(self.tables, string)
@@ -889,6 +895,8 @@ class HipEngine:
             ops.mv_fourpart_dequant(sym, common, sp, so_far, t)
         mv_y_hat = ops.mv_dequant(so_far, common)
         mv_hat, mv_feature = self.mv_dec(s, mv_y_hat, q_dec)
+        if me_downsample > 1:       # :516-517
+            mv_hat = ops.bilinear_up2(mv_hat, float(me_downsample), me_downsample)
         return {"mv_hat": mv_hat, "mv_feature": mv_feature, "mv_y_hat": mv_y_hat}
 
 

@@ -37,6 +37,8 @@ _SIGS = {
     "pmctf_avgpool2_f32": (ci, [vp, vp, ci, ci, ci, vp]),
     "pmctf_bilinear_up2_f32": (ci, [vp, vp, ci, ci, ci, cf, vp]),
     "pmctf_bilinear_down2_f32": (ci, [vp, vp, ci, ci, ci, cf, vp]),
+    "pmctf_bilinear_up_f32": (ci, [vp, vp, ci, ci, ci, ci, cf, vp]),
+    "pmctf_bilinear_down_f32": (ci, [vp, vp, ci, ci, ci, ci, cf, vp]),
     "pmctf_ew_f32": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp]),
     "pmctf_spynet_pack8_f32": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, vp]),

@@ -146,18 +146,21 @@ def avgpool2(x):
     return y
 
 
-def bilinear_up2(x, scale=1.0):
+def bilinear_up2(x, scale=1.0, factor=2):
+    """F.interpolate(bilinear, align_corners=False) to factor x the size (2, 4 or 8), result times `scale`"""
     N, Cc, H, W = x.shape
-    y = torch.empty((N, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.hip().pmctf_bilinear_up2_f32(_p(x), _p(y), N * Cc, H, W, float(scale), _stream()), "bilinear_up2")
+    y = torch.empty((N, Cc, factor * H, factor * W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.hip().pmctf_bilinear_up_f32(_p(x), _p(y), N * Cc, H, W, int(factor), float(scale), _stream()),
+               "bilinear_up")
     return y
 
 
-def bilinear_down2(x, div=1.0):
+def bilinear_down2(x, div=1.0, factor=2):
+    """F.interpolate(bilinear, align_corners=False) to 1/factor of the size (2, 4 or 8), result divided by `div`"""
     N, Cc, H, W = x.shape
-    y = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.hip().pmctf_bilinear_down2_f32(_p(x), _p(y), N * Cc, H, W, float(div), _stream()),
-               "bilinear_down2")
+    y = torch.empty((N, Cc, H // factor, W // factor), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.hip().pmctf_bilinear_down_f32(_p(x), _p(y), N * Cc, H, W, int(factor), float(div), _stream()),
+               "bilinear_down")
     return y
 
 

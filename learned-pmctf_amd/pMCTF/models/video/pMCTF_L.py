@@ -10,7 +10,8 @@ on host threads.  There is no CPU fallback: without a GPU and the built librarie
 Implemented: the write-stream encode branch (pMCTF_L.py:553-637) with skip_decoding True or False (real decoder:
 decompress_mv, decompress_one_stage), inverse_MCTF, the estimate-mode forward (forward / forward_one_stage at
 inference).  Not implemented (raise NotImplementedError): the estimate-only branch of encode_one_stage
-(output_path=None; broken in the reference itself), me_downsample > 1, training-mode forward.
+(output_path=None; broken in the reference itself), training-mode forward.  me_downsample in
+{1, 2, 4, 8} is supported everywhere (motion estimated and coded at reduced resolution).
 """
 import os
 import os.path as osp
@@ -126,12 +127,17 @@ class pMCTF(nn.Module):
         c = lambda t: t.contiguous()
         return self.engine().forward_MCTF(c(ref_frame), c(cur_frame), c(mv_hat), stage_idx)
 
+    @staticmethod
+    def _check_ds(me_downsample):
+        if me_downsample not in (1, 2, 4, 8):
+            raise ValueError("me_downsample must be 1, 2, 4 or 8")
+
     @torch.no_grad()
     def decompress_mv(self, string, dtype, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """pMCTF_L.py:497-523 — returns mv_hat (1,2,H,W) and the MV decoder contexts (logical NCHW views)"""
-        if me_downsample != 1:
-            raise NotImplementedError("me_downsample > 1")
-        d = self.engine().decompress_mv(string, height, width, dpb, stage_idx=stage_idx, q_index=q_index)
+        self._check_ds(me_downsample)
+        d = self.engine().decompress_mv(string, height, width, dpb, stage_idx=stage_idx, q_index=q_index,
+                                        me_downsample=me_downsample)
         return {"mv_hat": d["mv_hat"], "mv_feature": d["mv_feature"].permute(0, 3, 1, 2),
                 "mv_y_hat": d["mv_y_hat"].permute(0, 3, 1, 2)}
 
@@ -169,15 +175,14 @@ class pMCTF(nn.Module):
         """Estimate-mode stage (pMCTF_L.py:332-379): the same networks as encode_one_stage with Laplace / factorized
         bit estimates instead of range coding.  ref_frame / cur_frame are (N,1,H,W) planes (Y, or UV with the luma
         motion passed as mv_hat).  Scalars come back as 0-dim float32 CPU tensors (one device read per call)."""
-        if me_downsample != 1:
-            raise NotImplementedError("me_downsample > 1")
+        self._check_ds(me_downsample)
         if self.training:
             raise NotImplementedError("training forward (noise quantisation, gradients) is not part of this build")
         eng = self.engine()
         dev = next(self.parameters()).device
         ref, cur = ref_frame.to(dev).contiguous(), cur_frame.to(dev).contiguous()
         r = eng.forward_one_stage(ref, cur, q_index, code_lt, dpb, None if mv_hat is None else mv_hat.contiguous(),
-                                  stage_idx)
+                                  stage_idx, me_downsample)
         acc = r["acc"]
         keys = sorted(acc)
         vals = torch.cat([acc[k].reshape(-1).sum().reshape(1) for k in keys]).cpu().tolist()     # the one sync
@@ -214,8 +219,7 @@ class pMCTF(nn.Module):
         if output_path is None:
             raise NotImplementedError("estimate-only branch (output_path=None) is not part of this build "
                                       "(it raises KeyError in the reference as well)")
-        if me_downsample != 1:
-            raise NotImplementedError("me_downsample > 1")
+        self._check_ds(me_downsample)
         eng = self.engine()
         ref_y, ref_chroma = ref_frame
         cur_y, cur_chroma = cur_frame
@@ -224,7 +228,7 @@ class pMCTF(nn.Module):
         start = time.time()
         keep = eng.keep_streams
         mv_out = output_path.replace(".bin", "_mv.bin")
-        mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index)
+        mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index, me_downsample=me_downsample)
         jobs = {"mv": eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0), mv_out, keep)}
         mv_hat = mv["mv_hat"]
         base = osp.basename(output_path)
@@ -287,8 +291,11 @@ class pMCTF(nn.Module):
             # pMCTF_L.py:594-612: hand back what the decoder reconstructs from the files just written
             t0 = time.time()
             mv_y_q_index, string = decode_p(mv_out)
-            decoded = self.decompress_mv(string, ref_y.dtype, ref_y.size(2), ref_y.size(3), dpb, stage_idx=stage_idx,
-                                         q_index=q_index)
+            # (the reference passes the full-resolution size and no factor here, pMCTF_L.py:597-602, which cannot
+            # decode a reduced-resolution motion stream; the stream is decoded at the size it was coded at)
+            decoded = self.decompress_mv(string, ref_y.dtype, ref_y.size(2) // me_downsample,
+                                         ref_y.size(3) // me_downsample, dpb, stage_idx=stage_idx, q_index=q_index,
+                                         me_downsample=me_downsample)
             mv_hat = decoded["mv_hat"]
             mv_feature = decoded["mv_feature"].permute(0, 2, 3, 1)
             out_dec, out_dec_c = self._decompress_files([(output_path, False), (file_name_c, True)], code_lt, psize,

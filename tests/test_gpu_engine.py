@@ -287,3 +287,46 @@ def test_estimate_mode_forward(setup):
     f = net.lp_coder(L_t, 3)
     assert abs(float(f["bits_total"]) - oy["bit_L"]) <= 1e-6 * oy["bit_L"]
     assert_same(f["x_hat"], oy["L_t"], "pWave.forward x_hat")
+
+
+def test_reduced_resolution_motion(setup):
+    """me_downsample: motion estimated and coded at 1/2 (128x128, vs oracle and the real reference's files) and at 1/4
+    (256x256 with the decoder in the loop, vs oracle), plus the estimate-mode twin."""
+    import os
+    net, orc = setup
+    g = golden()
+    fr = frames(W, H, 2)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with tempfile.TemporaryDirectory() as td:
+        r = net.encode_one_stage(frd[0], frd[1], False, dpb, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                 pic_height=H, skip_decoding=True, stage_idx=0, q_index=3, me_downsample=2)
+        for n in ("1.bin", "1_mv.bin", "1_C_main.bin"):
+            assert open(os.path.join(td, n), "rb").read() == g[f"ds2.file.{n}"].tobytes(), n
+        from pMCTF.utils.stream_helper import decode_p
+        _, string = decode_p(os.path.join(td, "1_mv.bin"))
+    o = orc.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=W, pic_height=H, q_index=3, me_downsample=2)
+    for k in ("H_t", "H_tc", "mv_hat"):
+        assert_same(r[k], o[k], f"ds2 {k}")
+        assert np.abs(r[k].cpu().numpy() - g[f"ds2.{k}"]).max() < 2e-3
+    d = net.decompress_mv(string, torch.float32, H // 2, W // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
+    assert_same(d["mv_hat"], r["mv_hat"], "ds2 decoded mv_hat")
+    assert np.abs(d["mv_feature"].cpu().numpy() - g["ds2.dec.mv_feature"]).max() < 2e-3
+    e = net.forward_one_stage(frd[0][0], frd[1][0], 3, False, dpb, me_downsample=2)
+    oe = orc.forward_one_stage(fr[0][0], fr[1][0], 3, False, dpb, me_downsample=2)
+    for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse"):
+        assert abs(float(e[k]) - oe[k]) <= 1e-6 * max(1.0, abs(oe[k])), k
+        assert abs(float(e[k]) - float(g[f"ds2.est.{k}"])) <= 1e-4 * max(1.0, abs(float(g[f"ds2.est.{k}"]))), k
+    assert_same(e["mv_hat"], oe["mv_hat"], "ds2 estimate mv_hat")
+    # 1/4 resolution needs frames padded to 256 (test_pMCTF_CA.py:121); decoder in the loop
+    fr4 = frames(256, 256, 2, seed=3)
+    frd4 = [[y.cuda(), c.cuda()] for y, c in fr4]
+    with tempfile.TemporaryDirectory() as td:
+        r4 = net.encode_one_stage(frd4[0], frd4[1], False, dpb, output_path=os.path.join(td, "1.bin"), pic_width=256,
+                                  pic_height=256, psize=256, skip_decoding=False, stage_idx=0, q_index=5, me_downsample=4)
+    o4 = orc.encode_one_stage(fr4[0], fr4[1], False, dpb, pic_width=256, pic_height=256, psize=256, q_index=5,
+                              me_downsample=4, skip_decoding=False)
+    for k in o4["files"]:
+        assert r4["files"][k] == o4["files"][k], f"ds4 file {k}"
+    for k in ("H_t", "H_tc", "mv_hat"):
+        assert_same(r4[k], o4[k], f"ds4 {k}")

@@ -137,6 +137,11 @@ def test_resample_bitexact(cuda):
     assert_same(ops.avgpool2(xt).cpu().numpy(), clib.avgpool2(x), "avgpool2")
     assert_same(ops.bilinear_up2(xt, 2.0).cpu().numpy(), clib.bilinear_up2(x) * np.float32(2), "up2")
     assert_same(ops.bilinear_down2(xt, 2.0).cpu().numpy(), clib.bilinear_down2(x) / np.float32(2), "down2")
+    x = (r.standard_normal((1, 2, 40, 72), dtype=np.float32) * 10).astype(np.float32)       # me_downsample factors
+    xt = torch.from_numpy(x).cuda()
+    for f in (2, 4, 8):
+        assert_same(ops.bilinear_up2(xt, float(f), f).cpu().numpy(), clib.bilinear_up(x, f) * np.float32(f), f"up x{f}")
+        assert_same(ops.bilinear_down2(xt, 1.0, f).cpu().numpy(), clib.bilinear_down(x, f), f"down /{f}")
 
 
 @pytest.mark.parametrize("shape", [(1, 112, 44, 72, 112, 3, 1), (2, 64, 70, 100, 64, 3, 1), (1, 112, 264, 520, 112, 3, 1),
