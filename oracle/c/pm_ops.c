@@ -34,6 +34,7 @@ static void *pm_pf_worker(void *p) {
 static int pm_num_threads(void) {
     const char *e = getenv("PM_ORACLE_THREADS");
     long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (!e && n > 16) n = 16;   /* a process often owns fewer CPUs than are online (containers); more threads only hurt */
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return (int)n;

@@ -162,14 +162,15 @@ def test_still_image_coder_256(setup):
         assert_same(x_hat, ox, "still image x_hat")
         assert_same(dec, x_hat, "decoded still image vs encoder reconstruction")
         assert_same(dec, orc.pwave_decompress("lp_coder", odata, 64, 3), "decoded still image vs oracle decoder")
-        # three planes in one stream (the RGB branch, pWave.py:394-396,459-460,524-525)
+        # three planes in one stream (the RGB branch, pWave.py:394-396,459-460,524-525), 128x128
+        img = img[:, :, :128, :128].contiguous()
         rgb = torch.cat([img, img.flip(2), img.flip(3)], dim=1)
-        x3 = coder.compress(rgb.cuda(), [1, 3, 256, 256], fn, q_index=7, skip_decoding=False)
+        x3 = coder.compress(rgb.cuda(), [1, 3, 128, 128], fn, q_index=7, skip_decoding=False)
         d3 = coder.decompress(fn, padding=64, q_index=7)["x_hat"]
         planes = torch.cat([rgb[:, c:c + 1] for c in range(3)], dim=0)
-        o3, o3data, _ = orc.pwave_compress("lp_coder", planes, [1, 3, 256, 256], 7, None, skip_decoding=False)
+        o3, o3data, _ = orc.pwave_compress("lp_coder", planes, [1, 3, 128, 128], 7, None, skip_decoding=False)
         assert open(fn, "rb").read() == o3data
-        assert x3.shape == (1, 3, 256, 256) and d3.shape == (1, 3, 256, 256)
+        assert x3.shape == (1, 3, 128, 128) and d3.shape == (1, 3, 128, 128)
         assert_same(d3, x3, "decoded RGB vs encoder reconstruction")
         assert_same(torch.cat([x3[:, c:c + 1] for c in range(3)], dim=0), o3, "RGB x_hat vs oracle")
 
@@ -198,9 +199,10 @@ def test_two_me_stages_cropped_frame(cuda):
     assert r["bit_ME"] == o["bit_ME"] == 8 * len(o["files"]["mv"])
 
 
-@pytest.mark.parametrize("q_index", [0, 12, 20])
+@pytest.mark.parametrize("q_index", [0, 20])
 def test_rate_points_match_oracle(setup, q_index):
-    """RD sweep end points (q_index 0..20): one pair per rate point, files and reconstructions identical to the oracle."""
+    """RD sweep end points (q_index 0 and 20; 3 and 12 are covered by the other tests): one pair per rate point, files
+    and reconstructions identical to the oracle."""
     import os
     net, orc = setup
     fr = frames(W, H, 2, seed=7)
@@ -290,8 +292,8 @@ def test_estimate_mode_forward(setup):
 
 
 def test_reduced_resolution_motion(setup):
-    """me_downsample: motion estimated and coded at 1/2 (128x128, vs oracle and the real reference's files) and at 1/4
-    (256x256 with the decoder in the loop, vs oracle), plus the estimate-mode twin."""
+    """me_downsample: motion estimated and coded at 1/2 (128x128, vs oracle and the real reference's files, with the
+    standalone motion decoder and the estimate-mode twin) and at 1/4 (256x256, vs oracle; HIP decoder in the loop)."""
     import os
     net, orc = setup
     g = golden()
