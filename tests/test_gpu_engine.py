@@ -332,3 +332,33 @@ def test_reduced_resolution_motion(setup):
         assert r4["files"][k] == o4["files"][k], f"ds4 file {k}"
     for k in ("H_t", "H_tc", "mv_hat"):
         assert_same(r4[k], o4[k], f"ds4 {k}")
+
+
+def test_config_448x256_lifting_step(setup):
+    """BASELINE configs[1]: one temporal-lifting step (SpyNet, warp, predict/update, both spatial coders) on a 448x256
+    pair, num_me_stages=1 — every tensor, symbol file and bit count identical to the oracle."""
+    import os
+    net, orc = setup
+    w, h = 448, 256
+    fr = frames(w, h, 2, seed=21)
+    assert fr[0][0].shape[-2:] == (256, 512)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    est = net.engine().spynet(frd[1][0], frd[0][0])
+    assert_same(est, orc.spynet(fr[1][0].tile((1, 3, 1, 1)) / 255, fr[0][0].tile((1, 3, 1, 1)) / 255), "SpyNet flow")
+    L_t, H_t, pred, inv = net.forward_MCTF(frd[0][0], frd[1][0], est)
+    oL, oH, opred, oinv = orc.forward_MCTF(fr[0][0], fr[1][0], est.cpu())
+    for a, b, n in ((L_t, oL, "L_t"), (H_t, oH, "H_t"), (pred, opred, "prediction"), (inv, oinv, "update")):
+        assert_same(a, b, n)
+    with tempfile.TemporaryDirectory() as td:
+        r = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=w,
+                                 pic_height=h, skip_decoding=True, stage_idx=0, q_index=3)
+    o = orc.encode_one_stage(fr[0], fr[1], True, dpb, pic_width=w, pic_height=h, q_index=3)
+    for k in o["files"]:
+        assert r["files"][k] == o["files"][k], f"file {k}"
+    for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+        assert_same(r[k], o[k], k)
+    assert r["bit_H"] == o["bit_H"] and r["bit_L"] == o["bit_L"] and r["bit_ME"] == o["bit_ME"]
+    ref, cur = net.inverse_MCTF(r["L_t"], r["H_t"], r["mv_hat"])
+    oref, ocur = orc.inverse_MCTF(o["L_t"], o["H_t"], o["mv_hat"])
+    assert_same(ref, oref, "inverse_MCTF ref"); assert_same(cur, ocur, "inverse_MCTF cur")
