@@ -646,7 +646,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"V1", 0, false}, {"V2", 0, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"V1", 0, false}, {"V2", 0, false}};
 inline long knob(const char *name) {
     for (Knob &k : g_knobs)
         if (!strcmp(k.name, name)) {
@@ -751,6 +751,9 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
             const int rc = launch_res<MTP>(a, MB, st);
             if (rc != PMCTF_EINVAL) return rc;
         }
+        const long mnt = knob("MSPLIT_NT");
+        if (mnt == 2) return launch<1, 2, 1>(a, MTP * MB, st, 0, a.Ho);
+        if (mnt == 4 && a.S == 1) return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
         return launch<1, 1, 1>(a, MTP * MB, st, 0, a.Ho);
     }
     // (2) large planes, stride 1: 8x32 tiles.  The wave-private kernel holds 2 workgroups per CU = 512 slots; rows
