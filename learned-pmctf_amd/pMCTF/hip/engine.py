@@ -614,10 +614,11 @@ class HipEngine:
         ops.sqdiff_sum(x.contiguous(), x_hat, sq)
         return {"x_hat": x_hat, "subbands": hat, "bits": sink.bits, "sq_err": sq}
 
-    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False, estimate=False):
+    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False, estimate=False, defer=False):
         """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream).  ar_order: LL symbols in the sequential coder's
         order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555).
-        estimate=True: returns (x_hat, BitSink, quantised subbands) — see pwave_forward."""
+        estimate=True: returns (x_hat, BitSink, quantised subbands) — see pwave_forward.
+        defer=True: returns (synthesis, SymbolStream); synthesis() computes x_hat later."""
         q_scale, q_scale_ll = self.q_scales(coder, q_index, qp_scale)
         N, _, H, W = x.shape
         clip = 8192.0
@@ -649,15 +650,22 @@ class HipEngine:
                 s_hat = self.fusion_compress(f"{coder}.context_fusion.{lvl}.{sb}", s_curr, ctx, prev, stream)
                 hat[lvl][sb] = s_hat
                 context = self.ctx_forward_one_subband(coder, lstm_state, s_hat, sb, lvl)
-        out = None
-        rec_ll = ew(EW_DIVS, hat[self.L - 1]["ll"], alpha=q_scale_ll)
-        for lvl in range(self.L - 1, -1, -1):
-            sbs = {"ll": rec_ll}
-            for sb in ("lh", "hl", "hh"):
-                sbs[sb] = ew(EW_DIVS, hat[lvl][sb], alpha=q_scale)
-            out = self.backward_lift_2d(coder, sbs)
-            rec_ll = out
-        x_hat = self.post_process(coder, out, 256.0, 256.0)
+        def synthesis():
+            """dequantise, inverse DWT, post-process (pWave.py:446-455): needed for the reconstruction only, not for
+            the bitstream, so a caller may run it after the stream has been handed to the range coder"""
+            out = None
+            rec_ll = ew(EW_DIVS, hat[self.L - 1]["ll"], alpha=q_scale_ll)
+            for lvl in range(self.L - 1, -1, -1):
+                sbs = {"ll": rec_ll}
+                for sb in ("lh", "hl", "hh"):
+                    sbs[sb] = ew(EW_DIVS, hat[lvl][sb], alpha=q_scale)
+                out = self.backward_lift_2d(coder, sbs)
+                rec_ll = out
+            return self.post_process(coder, out, 256.0, 256.0)
+
+        if defer:
+            return synthesis, stream
+        x_hat = synthesis()
         if estimate:
             return x_hat, stream, hat
         return x_hat, stream
@@ -692,16 +700,34 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ a8 compress_one_stage (pMCTF_L.py:398-420)
-    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0, ar_order=False):
+    def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0, ar_order=False,
+                           on_stream=None, defer=False):
+        """on_stream(kind, SymbolStream): called as soon as a stream's symbols are complete (kind "H" / "L")"""
         if ischroma:
             mv_hat = ops.bilinear_down2(mv_hat, 2.0)
         L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
-        H_hat, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, ar_order)
-        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": H_hat, "H_stream": h_stream, "L_t_hat": None, "L_stream": None}
+        H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, ar_order, defer=True)
+        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "H_stream": h_stream, "L_t_hat": None, "L_stream": None}
+        if on_stream is not None:
+            on_stream("H", h_stream)
+        L_syn = None
         if code_lt:
-            out["L_t_hat"], out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index, None, ar_order)
-        return out
+            L_syn, out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index, None, ar_order, defer=True)
+            if on_stream is not None:
+                on_stream("L", out["L_stream"])
+
+        def finish():
+            """the reconstructions (synthesis transforms + post-processing), after every stream of the pair is with
+            the range coder: its tail overlaps with this GPU work instead of leaving the GPU idle"""
+            out["H_t_hat"] = H_syn()
+            if L_syn is not None:
+                out["L_t_hat"] = L_syn()
+            return out
+        if defer:
+            out["finish"] = finish
+            return out
+        return finish()
 
 
     # =================================================================================================

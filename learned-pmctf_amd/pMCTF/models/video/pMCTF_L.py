@@ -235,26 +235,27 @@ class pMCTF(nn.Module):
         file_name_c = output_path.replace(".bin", "_C_main.bin")
         ry, cy, rc, cc = c(ref_y), c(cur_y), c(ref_chroma), c(cur_chroma)
 
+        # Each stream goes to the range coder the moment its symbols are complete; the synthesis side of the four coders
+        # (inverse DWT + post-processing, needed only for the returned reconstructions) runs after all streams have
+        # been submitted, so the coder's tail overlaps with GPU work.
         def code_luma():
-            r = eng.compress_one_stage(ry, cy, code_lt, mv_hat, False, stage_idx, q_index, not skip_decoding)
-            jobs["H"] = eng.coder.submit(r["H_stream"], eng.tables,
-                                         lambda n: image_header(pic_height, pic_width, 1, n), output_path, keep)
-            if code_lt:
-                jobs["L"] = eng.coder.submit(r["L_stream"], eng.tables,
-                                             lambda n: image_header(pic_height, pic_width, 1, n),
-                                             output_path.replace(base, "0_main.bin"), keep)
-            return r
+            paths = {"H": output_path, "L": output_path.replace(base, "0_main.bin")}
+
+            def submit(kind, stream):
+                jobs[kind] = eng.coder.submit(stream, eng.tables, lambda n: image_header(pic_height, pic_width, 1, n),
+                                              paths[kind], keep)
+            return eng.compress_one_stage(ry, cy, code_lt, mv_hat, False, stage_idx, q_index, not skip_decoding,
+                                          on_stream=submit, defer=True)
 
         def code_chroma():
-            r = eng.compress_one_stage(rc, cc, code_lt, mv_hat, True, stage_idx, q_index, not skip_decoding)
-            jobs["Hc"] = eng.coder.submit(r["H_stream"], eng.tables,
-                                          lambda n: image_header(pic_height // 2, pic_width // 2, 2, n), file_name_c,
-                                          keep)
-            if code_lt:
-                jobs["Lc"] = eng.coder.submit(r["L_stream"], eng.tables,
-                                              lambda n: image_header(pic_height // 2, pic_width // 2, 2, n),
-                                              output_path.replace(base, "0_C_main.bin"), keep)
-            return r
+            paths = {"H": file_name_c, "L": output_path.replace(base, "0_C_main.bin")}
+
+            def submit(kind, stream):
+                jobs[kind + "c"] = eng.coder.submit(stream, eng.tables,
+                                                    lambda n: image_header(pic_height // 2, pic_width // 2, 2, n),
+                                                    paths[kind], keep)
+            return eng.compress_one_stage(rc, cc, code_lt, mv_hat, True, stage_idx, q_index, not skip_decoding,
+                                          on_stream=submit, defer=True)
 
         if eng.multi_stream:
             main = torch.cuda.current_stream()
@@ -264,7 +265,7 @@ class pMCTF(nn.Module):
             for side, fn in zip(eng.side_streams, (code_luma, code_chroma)):
                 side.wait_event(ready)
                 with torch.cuda.stream(side):
-                    outs.append(fn())
+                    outs.append(fn()["finish"]())
             for side in eng.side_streams:
                 main.wait_stream(side)
             luma, chroma = outs
@@ -275,6 +276,8 @@ class pMCTF(nn.Module):
         else:
             luma = code_luma()
             chroma = code_chroma()
+            luma["finish"]()
+            chroma["finish"]()
         t_enq = time.time() - start
         if eng.profile_host:
             torch.cuda.synchronize()
