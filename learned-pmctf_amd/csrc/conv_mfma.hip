@@ -629,6 +629,111 @@ __global__ __launch_bounds__(256) void conv_mfma_res_kernel(ConvArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// 16 -> 16 channels, 3x3 (the PredictUpdate trunk, lifting_1d.py:39-40, 45-47): one chunk, one cout tile, so all 36
+// weight fragments stay in registers and a wave is PERSISTENT: it walks over 4x16-pixel tiles (grid-stride), fetching
+// the next tile's patch into registers while the current one is multiplied, wave-private LDS, no barriers.  The layer
+// moves 128 B per pixel for 9.2 kFLOP, i.e. it is HBM-bound once the weights stop being re-read.  Same sums, same order.
+__global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int tiles_total) {
+    constexpr int NT = 4, LH = 6, LW = 18, E = LH * LW * 4, MAXP = (E + 63) / 64;      // 432 float4 slots, 7 per lane
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int bufsz = LH * LW * CP;
+    float *wlds = lds + wave * 2 * bufsz;
+    const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;         // in 4x16 wave tiles
+    const int per_img = tiles_x * tiles_y;
+
+    f32x4 af[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) af[t] = *(const f32x4 *)(a.wp + t * 256 + lane * 4);
+    const f32x4 bias = *(const f32x4 *)(a.bp + 4 * (lane >> 4));
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (nt * LW + (lane & 15)) * CP + (lane >> 4);
+
+    f32x4 pre[MAXP];
+    auto fetch = [&](int tile) {
+        const int n = tile / per_img, r = tile - n * per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy0 = ty * 4 - 1, ix0 = tx * 16 - 1;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = lane + 64 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < E) {
+                const int pix = e >> 2, part = e & 3;
+                const int ly = pix / LW, lx = pix - ly * LW;
+                const int gy = iy0 + ly, gx = ix0 + lx;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * 16 + part * 4);
+            }
+            pre[j] = v;
+        }
+    };
+    auto stash = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = lane + 64 * j;
+            if (e < E) {
+                float2 *dst = (float2 *)(buf + (e >> 2) * CP + (e & 3) * 4);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+
+    const int stride = gridDim.x * WAVES;
+    int tile = blockIdx.x * WAVES + wave;
+    if (tile >= tiles_total) return;
+    fetch(tile);
+    stash(wlds);
+    int parity = 0;
+    for (; tile < tiles_total; tile += stride) {
+        const float *cur = wlds + parity * bufsz;
+        const bool more = tile + stride < tiles_total;
+        if (more) fetch(tile + stride);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float *bb = cur + ((t / 3) * LW + (t % 3)) * CP;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = bb[boff[nt] + ks * 4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
+            }
+        }
+        {
+            const int n = tile / per_img, r = tile - n * per_img;
+            const int ty = r / tiles_x, tx = r - ty * tiles_x;
+            const int ox = tx * 16 + (lane & 15);
+            const int co = 4 * (lane >> 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = ty * 4 + nt;
+                if (oy < a.Ho && ox < a.Wo) {
+                    const size_t o = (((size_t)n * a.Ho + oy) * a.Wo + ox) * 16 + co;
+                    f32x4 v = acc[nt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+                    if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + o); v = v + r1; }
+                    if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + o); v = v + r2; }
+                    *(f32x4 *)(a.y + o) = v;
+                }
+            }
+        }
+        if (more) stash(wlds + (parity ^ 1) * bufsz);
+        parity ^= 1;
+    }
+}
+
+
 // choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
 void choose_mt(int Cout, int &MT, int &MB) {
     const int tiles = (Cout + 15) / 16;
@@ -646,7 +751,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"V1", 0, false}, {"V2", 0, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}};
 inline long knob(const char *name) {
     for (Knob &k : g_knobs)
         if (!strcmp(k.name, name)) {
@@ -739,6 +844,24 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     if (force_nt == 4 && MTP < 8 && a.S == 1) return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);
     if (force_nt == 2) return launch<MTP, 2, 1>(a, MB, st, 0, a.Ho);
     if (force_nt == 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+    // (0) 16 -> 16 channels 3x3 'same' (PredictUpdate trunk): persistent kernel with register-resident weights
+    if constexpr (MTP == 1) {
+        if (knob("C16") != 0 && a.Cin == 16 && a.Cout == 16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.pad_h == 1 &&
+            a.pad_w == 1 && a.Ho == a.H && a.Wo == a.W && px >= 16384) {
+            ConvArgs b = a;
+            b.tiles_x = (a.Wo + 15) / 16;
+            b.tiles_y = (a.Ho + 3) / 4;
+            const long tiles = (long)b.tiles_x * b.tiles_y * a.N;
+            if (tiles < (1L << 30)) {
+                long wgs = (tiles + WAVES - 1) / WAVES;
+                const long cap = knob("C16_WGS");
+                if (wgs > cap) wgs = cap;
+                const size_t smem = (size_t)6 * 18 * CP * sizeof(float) * 2 * WAVES;
+                PM_LAUNCH(conv16_persistent_kernel, dim3((unsigned)wgs), dim3(256), smem, st, b, (int)tiles);
+                return pm_launch_status();
+            }
+        }
+    }
     // (1) small planes: too few 16-pixel segments to occupy 1024 SIMDs with whole M-blocks -> one cout tile per
     //     workgroup, MTP x more (and MTP x shorter) workgroups.  Same sums, same order.
     const long msplit_px = knob("MSPLIT_PX");

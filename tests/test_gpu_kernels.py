@@ -38,6 +38,8 @@ CONV_CASES = [
     (1, 16, 72, 120, 2, 7, 1, 3, 0, 0.0, 0),       # SpyNet conv5 (Cout=2)
     (1, 16, 64, 64, 1, 3, 1, 1, 0, 0.0, 0),        # PredictUpdate conv4
     (1, 16, 64, 64, 16, 3, 1, 1, 3, 0.0, 0),       # PredictUpdate conv2 + tanh
+    (2, 16, 150, 203, 16, 3, 1, 1, 3, 0.0, 0),     # persistent 16->16 kernel: ragged tiles, two planes, tanh
+    (1, 16, 129, 130, 16, 3, 1, 1, 0, 0.0, 1),     # persistent 16->16 kernel: residual add
     (1, 64, 64, 96, 64, 3, 2, 1, 2, 0.01, 0),      # stride-2 3x3
     (1, 64, 64, 96, 64, 1, 2, 0, 0, 0.0, 0),       # stride-2 1x1 (downsample)
     (1, 256, 18, 30, 192, 1, 1, 0, 0, 0.0, 0),     # four-part prior adaptor 1x1 256->192
@@ -145,6 +147,7 @@ def test_resample_bitexact(cuda):
 
 
 @pytest.mark.parametrize("shape", [(1, 112, 44, 72, 112, 3, 1), (2, 64, 70, 100, 64, 3, 1), (1, 112, 264, 520, 112, 3, 1),
+                                   (1, 16, 140, 150, 16, 3, 1),
                                    (1, 32, 48, 80, 64, 7, 1), (1, 64, 64, 96, 128, 3, 2)])
 def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     """Every way of cutting a convolution into workgroups (cout-tile split, row split, tile size, kernel variant)
@@ -160,11 +163,12 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2))
     xd = nhwc(x)
     L = lib.hip()
-    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0}
+    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1, "C16": 1, "C16_WGS": 512}
     settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
-                {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}]
+                {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}, {"MSPLIT_NT": 2, "MSPLIT_PX": 1 << 40},
+                {"MSPLIT_NT": 4, "MSPLIT_PX": 1 << 40}, {"C16": 0}, {"C16_WGS": 3}]
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():
