@@ -179,7 +179,7 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
                     const float mean = prm[pl][1];
                     s = s < 1e-5f ? 1e-5f : s;
                     float iv = (pm::logf_(s) - a.lmin) / a.lstep;
-                    iv = iv < 0.0f ? 0.0f : iv;
+                    iv = iv >= 0.0f ? iv : 0.0f;          // also maps NaN (corrupt stream) to row 0
                     iv = iv > 255.0f ? 255.0f : iv;
                     const int row = (int)iv;
                     const int32_t *cd = a.cdf + (long)row * a.cols;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
 __device__ __forceinline__ int scale_index(float s, float lmin, float step) {
     s = s < 1e-5f ? 1e-5f : s;
     float v = (pm::logf_(s) - lmin) / step;
-    v = v < 0.0f ? 0.0f : v;
+    v = v >= 0.0f ? v : 0.0f;      // also maps NaN (corrupt stream) to row 0
     v = v > 255.0f ? 255.0f : v;
     return (int)v;
 }

@@ -153,7 +153,7 @@ __global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__r
 __device__ __forceinline__ int scale_index(float s, float lmin, float step) {
     s = s < 1e-5f ? 1e-5f : s;   // torch.maximum(scales, 1e-5)
     float v = (pm::logf_(s) - lmin) / step;
-    v = v < 0.0f ? 0.0f : v;
+    v = v >= 0.0f ? v : 0.0f;      // also maps NaN to row 0 instead of an out-of-range row
     v = v > 255.0f ? 255.0f : v;
     return (int)v;
 }

@@ -362,3 +362,36 @@ def test_config_448x256_lifting_step(setup):
     ref, cur = net.inverse_MCTF(r["L_t"], r["H_t"], r["mv_hat"])
     oref, ocur = orc.inverse_MCTF(o["L_t"], o["H_t"], o["mv_hat"])
     assert_same(ref, oref, "inverse_MCTF ref"); assert_same(cur, ocur, "inverse_MCTF cur")
+
+
+def test_corrupt_streams_fail_cleanly(setup):
+    """A truncated or garbled file must end in an exception or in (wrong) pixels, never in a fault or a hang: CDF rows
+    are clamped (NaN included), every stream read is bounds-checked on the host and inside the LL kernel."""
+    import os
+    net, _ = setup
+    img = frames(128, 128, 1)[0][0]
+    coder = net.lp_coder
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "img.bin")
+        coder.compress(img.cuda(), [1, 1, 128, 128], fn, q_index=3, skip_decoding=False)
+        good = open(fn, "rb").read()
+        rng = np.random.default_rng(0)
+        import struct
+        cases = {
+            "truncated": good[:16 + (len(good) - 16) // 3],
+            "garbled payload": good[:24] + rng.integers(0, 256, len(good) - 24, dtype=np.uint8).tobytes(),
+            "length field too long": good[:12] + struct.pack(">I", len(good) * 2) + good[16:],
+        }
+        for name, data in cases.items():
+            if name == "truncated":      # keep the header's length field consistent with what is there
+                data = data[:12] + struct.pack(">I", len(data) - 16) + data[16:]
+            open(fn, "wb").write(data)
+            try:
+                out = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
+                torch.cuda.synchronize()
+                assert out.shape == (1, 1, 128, 128), name
+            except (ValueError, RuntimeError):
+                pass
+        open(fn, "wb").write(good)       # and the coder still works afterwards
+        again = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
+        assert torch.isfinite(again).all()
