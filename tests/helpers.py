@@ -47,3 +47,9 @@ def assert_same(a, b, what):
         i = tuple(np.argwhere(neq)[0])
         raise AssertionError(f"{what}: {int(neq.sum())}/{a.size} elements differ; first at {i}: {a[i]!r} vs {b[i]!r}; "
                              f"max abs diff {np.abs(a.astype(np.float64) - b.astype(np.float64)).max():.3e}")
+
+
+def golden_448():
+    """files / bit counts / PSNR of the real reference on the 448x256 GOP-4 (tools/make_golden.py --width 448 --height 256,
+    reduced to the arrays that are not full-size tensors)"""
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_448x256_files.npz"))

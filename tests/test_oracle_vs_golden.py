@@ -132,3 +132,30 @@ def test_half_resolution_motion(sd, backend, ttol):
             ref = float(g[f"ds2.est.{k}"])
             assert abs(e[k] - ref) <= 2e-5 * max(1.0, abs(ref)), (k, e[k], ref)
         assert _close(e["mv_hat"], g["ds2.est.mv_hat"], ttol) and _close(e["H_t"], g["ds2.est.H_t"], ttol)
+
+
+def test_gop4_448x256_torch_backend(sd):
+    """A second size against the real reference (padded 512x256 planes, GOP-4 through the harness loop): per-frame
+    bits, every bitstream file and PSNR identical."""
+    import pmctf_gop
+    from helpers import golden_448
+    from pmctf_oracle.model import Oracle
+    g = golden_448()
+    o = Oracle(sd, 1, "torch")
+    w, h = 448, 256
+    fr = frames(w, h, 4)
+    with tempfile.TemporaryDirectory() as td, torch.no_grad():
+        enc = pmctf_gop.encode_gop(o, fr, h, w, 3, td)
+        rec = pmctf_gop.decode_gop(o, enc["frames_coded"])
+        ps = pmctf_gop.gop_psnr(rec, fr, h, w)
+    assert enc["bits"] == g["gop.bits"].tolist() and enc["bits_mv"] == g["gop.bits_mv"].tolist()
+    assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
+    n = 0
+    for i, r in enumerate(enc["results"]):
+        cur = int(g[f"gop.pair{i}.meta"][2])
+        for name, key in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin"),
+                          ("L", "0_main.bin"), ("Lc", "0_C_main.bin")):
+            if name in r["files"] and f"gop.pair{i}.file.{key}" in g.files:
+                assert r["files"][name] == g[f"gop.pair{i}.file.{key}"].tobytes(), (i, name)
+                n += 1
+    assert n >= 11

@@ -119,7 +119,8 @@ def main():
     with torch.no_grad():
         # ---- unit level (a4, a5, a6, a3) ------------------------------------------------------
         from pMCTF.layers.video.video_net import flow_warp, bilinearupsacling, bilineardownsacling
-        flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, H, W), 3.0))
+        PH, PW = Y0.shape[-2:]              # frames are zero-padded to multiples of 128
+        flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, PH, PW), 3.0))
         out["unit.flow"] = flow.numpy()
         out["unit.warp"] = flow_warp(Y0, flow).numpy()
         out["unit.predict_filter"] = net.temporal_filtering[0].predict_filter(Y0).numpy()
@@ -224,7 +225,7 @@ def main():
             for k in ("H_t", "H_tc", "mv_hat"):
                 out[f"ds2.{k}"] = r[k].numpy().copy()
             _, string = decode_p(os.path.join(td, "1_mv.bin"))
-            d = net.decompress_mv(string, torch.float32, H // 2, W // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
+            d = net.decompress_mv(string, torch.float32, PH // 2, PW // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
             out["ds2.dec.mv_hat"] = d["mv_hat"].numpy().copy()
             out["ds2.dec.mv_feature"] = d["mv_feature"].numpy().copy()
             e = net.forward_one_stage(Y0, Y1, 3, False, dpb, me_downsample=2)
