@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--width", type=int, default=128)
     ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--gop_only", action="store_true", help="only the GOP-4 harness loop (files, bits, PSNR)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -117,39 +118,40 @@ def main():
     Y1, C1 = frames[1]
 
     with torch.no_grad():
-        # ---- unit level (a4, a5, a6, a3) ------------------------------------------------------
-        from pMCTF.layers.video.video_net import flow_warp, bilinearupsacling, bilineardownsacling
-        PH, PW = Y0.shape[-2:]              # frames are zero-padded to multiples of 128
-        flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, PH, PW), 3.0))
-        out["unit.flow"] = flow.numpy()
-        out["unit.warp"] = flow_warp(Y0, flow).numpy()
-        out["unit.predict_filter"] = net.temporal_filtering[0].predict_filter(Y0).numpy()
-        out["unit.update_filter"] = net.temporal_filtering[0].update_filter(Y1 - Y0).numpy()
-        L_t, H_t, pred, inv = net.forward_MCTF(Y0, Y1, flow)
-        out["unit.mctf.L"], out["unit.mctf.H"] = L_t.numpy(), H_t.numpy()
-        Lc, Hc, _, _ = net.forward_MCTF(C0, C1, bilineardownsacling(flow) / 2)
-        out["unit.mctf.Lc"], out["unit.mctf.Hc"] = Lc.numpy(), Hc.numpy()
-        r, c = net.inverse_MCTF(L_t, H_t, flow)
-        out["unit.imctf.ref"], out["unit.imctf.cur"] = r.numpy(), c.numpy()
-        est = net.optic_flow(Y1.tile((1, 3, 1, 1)) / 255, Y0.tile((1, 3, 1, 1)) / 255)
-        out["unit.spynet"] = est.numpy()
-        sb = net.hp_coder.wavelet_transform.forward_lift_2d(H_t)
-        for k in ("ll", "lh", "hl", "hh"):
-            out[f"unit.dwt.{k}"] = sb[k].contiguous().numpy()
-        out["unit.idwt"] = net.hp_coder.wavelet_transform.backward_lift_2d(sb).numpy()
-        out["unit.postprocess"] = net.hp_coder.dequantModule(H_t / 256.0).numpy()
+        if not args.gop_only:
+            # ---- unit level (a4, a5, a6, a3) ------------------------------------------------------
+            from pMCTF.layers.video.video_net import flow_warp, bilinearupsacling, bilineardownsacling
+            PH, PW = Y0.shape[-2:]              # frames are zero-padded to multiples of 128
+            flow = torch.from_numpy(pmctf_synth.hashed_normal("golden.flow", (1, 2, PH, PW), 3.0))
+            out["unit.flow"] = flow.numpy()
+            out["unit.warp"] = flow_warp(Y0, flow).numpy()
+            out["unit.predict_filter"] = net.temporal_filtering[0].predict_filter(Y0).numpy()
+            out["unit.update_filter"] = net.temporal_filtering[0].update_filter(Y1 - Y0).numpy()
+            L_t, H_t, pred, inv = net.forward_MCTF(Y0, Y1, flow)
+            out["unit.mctf.L"], out["unit.mctf.H"] = L_t.numpy(), H_t.numpy()
+            Lc, Hc, _, _ = net.forward_MCTF(C0, C1, bilineardownsacling(flow) / 2)
+            out["unit.mctf.Lc"], out["unit.mctf.Hc"] = Lc.numpy(), Hc.numpy()
+            r, c = net.inverse_MCTF(L_t, H_t, flow)
+            out["unit.imctf.ref"], out["unit.imctf.cur"] = r.numpy(), c.numpy()
+            est = net.optic_flow(Y1.tile((1, 3, 1, 1)) / 255, Y0.tile((1, 3, 1, 1)) / 255)
+            out["unit.spynet"] = est.numpy()
+            sb = net.hp_coder.wavelet_transform.forward_lift_2d(H_t)
+            for k in ("ll", "lh", "hl", "hh"):
+                out[f"unit.dwt.{k}"] = sb[k].contiguous().numpy()
+            out["unit.idwt"] = net.hp_coder.wavelet_transform.backward_lift_2d(sb).numpy()
+            out["unit.postprocess"] = net.hp_coder.dequantModule(H_t / 256.0).numpy()
 
-        # ---- one pWave.compress (a9) ----------------------------------------------------------
-        with tempfile.TemporaryDirectory() as td:
-            trace.clear()
-            fn = os.path.join(td, "x.bin")
-            qp_scale = net.get_curr_q(net.hp_q_scale[0], 3)
-            x_hat = net.hp_coder.compress(H_t, [1, 1, H, W], fn, q_index=3, skip_decoding=True, qp_scale=qp_scale)
-            out["pwave.x_hat"] = x_hat.numpy()
-            out["pwave.file"] = np.frombuffer(open(fn, "rb").read(), dtype=np.uint8)
-            out["pwave.symbols"] = np.concatenate([t[0] for t in trace])
-            out["pwave.indexes"] = np.concatenate([t[1] for t in trace])
-            out["pwave.push_sizes"] = np.array([t[0].size for t in trace], np.int64)
+            # ---- one pWave.compress (a9) ----------------------------------------------------------
+            with tempfile.TemporaryDirectory() as td:
+                trace.clear()
+                fn = os.path.join(td, "x.bin")
+                qp_scale = net.get_curr_q(net.hp_q_scale[0], 3)
+                x_hat = net.hp_coder.compress(H_t, [1, 1, H, W], fn, q_index=3, skip_decoding=True, qp_scale=qp_scale)
+                out["pwave.x_hat"] = x_hat.numpy()
+                out["pwave.file"] = np.frombuffer(open(fn, "rb").read(), dtype=np.uint8)
+                out["pwave.symbols"] = np.concatenate([t[0] for t in trace])
+                out["pwave.indexes"] = np.concatenate([t[1] for t in trace])
+                out["pwave.push_sizes"] = np.array([t[0].size for t in trace], np.int64)
 
         # ---- a GOP-4 through the harness loop (a1, a2, a7, a8) ----------------------------------
         with tempfile.TemporaryDirectory() as td:
@@ -185,52 +187,53 @@ def main():
             for i, (ry, rc, _) in enumerate(rec_frames):
                 out[f"gop.rec{i}.y"] = ry.numpy()
 
-        # ---- one pair with the real decoder in the loop (skip_decoding=False, pMCTF_L.py:594-612) ------------
-        with tempfile.TemporaryDirectory() as td:
-            trace.clear()
-            dpb = {"mv_feature": None, "ref_mv_y": None}
-            r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
-                                     pic_height=H, pic_width=W, stage_idx=0, code_lt=True, psize=128,
-                                     skip_decoding=False, dpb=dpb, q_index=3)
-            for name in sorted(os.listdir(td)):
-                out[f"dec.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
-            for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
-                out[f"dec.{k}"] = r[k].numpy().copy()
-            out["dec.mv_feature"] = r["dpb"]["mv_feature"].numpy().copy()
-            out["dec.bits"] = np.array([r["bit_H"], r["bit_L"], r["bit_ME"]], np.float64)
+        if not args.gop_only:
+            # ---- one pair with the real decoder in the loop (skip_decoding=False, pMCTF_L.py:594-612) ------------
+            with tempfile.TemporaryDirectory() as td:
+                trace.clear()
+                dpb = {"mv_feature": None, "ref_mv_y": None}
+                r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
+                                         pic_height=H, pic_width=W, stage_idx=0, code_lt=True, psize=128,
+                                         skip_decoding=False, dpb=dpb, q_index=3)
+                for name in sorted(os.listdir(td)):
+                    out[f"dec.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
+                for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+                    out[f"dec.{k}"] = r[k].numpy().copy()
+                out["dec.mv_feature"] = r["dpb"]["mv_feature"].numpy().copy()
+                out["dec.bits"] = np.array([r["bit_H"], r["bit_L"], r["bit_ME"]], np.float64)
 
-        # ---- estimate-mode forward (pMCTF_L.py:332-379): luma with motion estimation, chroma with the luma motion ------
-        dpb = {"mv_feature": None, "ref_mv_y": None}
-        ry = net.forward_one_stage(Y0, Y1, 3, True, dpb)
-        rc = net.forward_one_stage(C0, C1, 3, True, dpb, mv_hat=ry["mv_hat"])
-        rn = net.forward_one_stage(Y0, Y1, 12, False, ry["dpb"], stage_idx=0)      # no L coding, dpb from a coded pair
-        for tag, d in (("y", ry), ("c", rc), ("n", rn)):
-            for k, v in d.items():
-                if k == "dpb":
-                    for kk, vv in v.items():
-                        if vv is not None:
-                            out[f"est.{tag}.dpb.{kk}"] = vv.numpy().copy()
-                elif v is not None:
-                    out[f"est.{tag}.{k}"] = np.asarray(v.detach().numpy()).copy()
-
-        # ---- motion estimated and coded at half resolution (me_downsample=2, pMCTF_L.py:456-458,475-476,516-517) ------
-        with tempfile.TemporaryDirectory() as td:
-            from pMCTF.utils.stream_helper import decode_p
+            # ---- estimate-mode forward (pMCTF_L.py:332-379): luma with motion estimation, chroma with the luma motion ------
             dpb = {"mv_feature": None, "ref_mv_y": None}
-            r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
-                                     pic_height=H, pic_width=W, stage_idx=0, code_lt=False, psize=128,
-                                     skip_decoding=True, dpb=dpb, q_index=3, me_downsample=2)
-            for name in sorted(os.listdir(td)):
-                out[f"ds2.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
-            for k in ("H_t", "H_tc", "mv_hat"):
-                out[f"ds2.{k}"] = r[k].numpy().copy()
-            _, string = decode_p(os.path.join(td, "1_mv.bin"))
-            d = net.decompress_mv(string, torch.float32, PH // 2, PW // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
-            out["ds2.dec.mv_hat"] = d["mv_hat"].numpy().copy()
-            out["ds2.dec.mv_feature"] = d["mv_feature"].numpy().copy()
-            e = net.forward_one_stage(Y0, Y1, 3, False, dpb, me_downsample=2)
-            for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse", "mv_hat", "H_t"):
-                out[f"ds2.est.{k}"] = np.asarray(e[k].detach().numpy()).copy()
+            ry = net.forward_one_stage(Y0, Y1, 3, True, dpb)
+            rc = net.forward_one_stage(C0, C1, 3, True, dpb, mv_hat=ry["mv_hat"])
+            rn = net.forward_one_stage(Y0, Y1, 12, False, ry["dpb"], stage_idx=0)      # no L coding, dpb from a coded pair
+            for tag, d in (("y", ry), ("c", rc), ("n", rn)):
+                for k, v in d.items():
+                    if k == "dpb":
+                        for kk, vv in v.items():
+                            if vv is not None:
+                                out[f"est.{tag}.dpb.{kk}"] = vv.numpy().copy()
+                    elif v is not None:
+                        out[f"est.{tag}.{k}"] = np.asarray(v.detach().numpy()).copy()
+
+            # ---- motion estimated and coded at half resolution (me_downsample=2, pMCTF_L.py:456-458,475-476,516-517) ------
+            with tempfile.TemporaryDirectory() as td:
+                from pMCTF.utils.stream_helper import decode_p
+                dpb = {"mv_feature": None, "ref_mv_y": None}
+                r = net.encode_one_stage(ref_frame=frames[0], cur_frame=frames[1], output_path=os.path.join(td, "1.bin"),
+                                         pic_height=H, pic_width=W, stage_idx=0, code_lt=False, psize=128,
+                                         skip_decoding=True, dpb=dpb, q_index=3, me_downsample=2)
+                for name in sorted(os.listdir(td)):
+                    out[f"ds2.file.{name}"] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
+                for k in ("H_t", "H_tc", "mv_hat"):
+                    out[f"ds2.{k}"] = r[k].numpy().copy()
+                _, string = decode_p(os.path.join(td, "1_mv.bin"))
+                d = net.decompress_mv(string, torch.float32, PH // 2, PW // 2, dpb, stage_idx=0, q_index=3, me_downsample=2)
+                out["ds2.dec.mv_hat"] = d["mv_hat"].numpy().copy()
+                out["ds2.dec.mv_feature"] = d["mv_feature"].numpy().copy()
+                e = net.forward_one_stage(Y0, Y1, 3, False, dpb, me_downsample=2)
+                for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse", "mv_hat", "H_t"):
+                    out[f"ds2.est.{k}"] = np.asarray(e[k].detach().numpy()).copy()
 
     path = os.path.join(args.out, f"reference_{W}x{H}.npz")
     np.savez_compressed(path, **out)
