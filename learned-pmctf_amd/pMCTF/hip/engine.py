@@ -153,6 +153,9 @@ class HipEngine:
         self._convs = {}
         self._dw = {}
         self._lin = {}
+        self._dev_tab = {}      # CDF tables on the device (decoder)
+        self._llw = {}          # packed masked weights of the sequential LL network, per coder (decoder)
+        self._bitparm = {}      # per-channel constants of the factorized prior (estimate mode)
         # entropy tables: name -> (cdf int32 [R,C], sizes int32 [R], offsets int32 [R]) host arrays
         self.tables = {"gauss": tuple(np.ascontiguousarray(a, dtype=np.int32) for a in gaussian_tables["cdf_info"])}
         for i, t in enumerate(bit_est_tables):
@@ -376,8 +379,6 @@ class HipEngine:
     def bitparm_consts(self, s):
         """per-channel constants of the factorized prior (entropy_models.py:72-77), evaluated on the host like the
         other scalar parameters: rows softplus(h) f1..f4, b f1..f4, tanh(a) f1..f3"""
-        if not hasattr(self, "_bitparm"):
-            self._bitparm = {}
         c = self._bitparm.get(s)
         if c is None:
             import torch.nn.functional as F
@@ -735,10 +736,8 @@ class HipEngine:
     # (libpmctf_rans.so) except for the sequential LL subband, which is decoded inside one persistent kernel.
     # =================================================================================================
     def _dev_tables(self, name):
-        t = self._dev_tab.get(name) if hasattr(self, "_dev_tab") else None
+        t = self._dev_tab.get(name)
         if t is None:
-            if not hasattr(self, "_dev_tab"):
-                self._dev_tab = {}
             cdf, sizes, offsets = self.tables[name]
             t = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (cdf, sizes, offsets))
             torch.cuda.synchronize(self.dev)
@@ -746,8 +745,6 @@ class HipEngine:
         return t
 
     def _ll_weights(self, coder):
-        if not hasattr(self, "_llw"):
-            self._llw = {}
         w = self._llw.get(coder)
         if w is None:
             p = f"{coder}.context_fusion.{self.L - 1}.ll"

@@ -1,5 +1,6 @@
 """HIP product (through the drop-in pMCTF API) vs the oracle's PM-F32 restatement: bit-exact tensors, identical
 symbol streams and identical bitstream bytes; and vs the fixtures generated from the real reference."""
+import os
 import tempfile
 
 import numpy as np
@@ -429,3 +430,34 @@ def test_gop4_448x256_vs_reference(setup):
                 else:
                     diff += 1
     assert same >= 10 and diff <= 1, (same, diff)
+
+
+def test_gop4_960x544_vs_reference(setup):
+    """The same bar at a quarter of 1080p (planes padded to 1024x640), against digests of the real reference's GOP-4
+    output (tools/make_golden.py --width 960 --height 544 --gop_only; file bytes reduced to SHA-1 + length)."""
+    import hashlib
+    import pmctf_gop
+    net, _ = setup
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_960x544_digest.npz"))
+    w, h = 960, 544
+    fr = frames(w, h, 4, device="cuda")
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_gop.encode_gop(net, fr, h, w, 3, td)
+        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+        ps = pmctf_gop.gop_psnr(rec, fr, h, w)
+    assert enc["bits"] == g["gop.bits"].tolist(), "bits per frame differ from the reference"
+    assert enc["bits_mv"] == g["gop.bits_mv"].tolist()
+    assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
+    same = diff = 0
+    for i, r in enumerate(enc["results"]):
+        cur = int(g[f"gop.pair{i}.meta"][2])
+        for name, key in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin"),
+                          ("L", "0_main.bin"), ("Lc", "0_C_main.bin")):
+            k = f"gop.pair{i}.filesha1.{key}"
+            if name in r["files"] and k in g.files:
+                assert len(r["files"][name]) == int(g[k.replace("filesha1", "filelen")]), (i, name)
+                if hashlib.sha1(r["files"][name]).digest() == g[k].tobytes():
+                    same += 1
+                else:
+                    diff += 1
+    assert same >= 9 and diff <= 2, (same, diff)
