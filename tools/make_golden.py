@@ -80,7 +80,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--width", type=int, default=128)
     ap.add_argument("--height", type=int, default=128)
-    ap.add_argument("--gop_only", action="store_true", help="only the GOP-4 harness loop (files, bits, PSNR)")
+    ap.add_argument("--gop_only", action="store_true", help="only the GOP harness loop (files, bits, PSNR)")
+    ap.add_argument("--gop", type=int, default=4, help="GOP size of the harness loop")
+    ap.add_argument("--me_stages", type=int, default=1, help="num_me_stages of the model")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -97,12 +99,12 @@ def main():
 
     EntropyCoder.encode_with_indexes = rec
 
-    net = pMCTF(num_me_stages=1).eval()
+    net = pMCTF(num_me_stages=args.me_stages).eval()
     template = net.state_dict()
     # boundary contract: key names + shapes of the parameter tree
     import json
     for n in (1, 2):
-        t = template if n == 1 else pMCTF(num_me_stages=2).state_dict()
+        t = pMCTF(num_me_stages=n).state_dict()
         json.dump({k: list(v.shape) for k, v in t.items()}, open(os.path.join(args.out, f"state_dict_keys_me{n}.json"), "w"))
     sd = pmctf_synth.synth_state_dict(template, seed=0)
     net.load_state_dict(sd, strict=True)
@@ -112,7 +114,7 @@ def main():
             "torch": torch.__version__}
 
     W, H = args.width, args.height
-    frames8 = pmctf_synth.synth_yuv420(W, H, 4, seed=1234)
+    frames8 = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234)
     frames = [list(pmctf_synth.frames_to_tensors(f)) for f in frames8]
     Y0, C0 = frames[0]
     Y1, C1 = frames[1]
@@ -159,6 +161,20 @@ def main():
 
             def on_pair(stage_idx, i_ref, i_cur, r):
                 files = {}
+                if args.gop_only and args.gop > 4:      # large runs: digests of the files this pair wrote, no tensors
+                    names = [f"{i_cur}.bin", f"{i_cur}_mv.bin", f"{i_cur}_C_main.bin"]
+                    if r["bit_L"] is not None:
+                        names += ["0_main.bin", "0_C_main.bin"]
+                    i = len(per_pair)
+                    for name in names:
+                        data = open(os.path.join(td, name), "rb").read()
+                        out[f"gop.pair{i}.filesha1.{name}"] = np.frombuffer(hashlib.sha1(data).digest(), dtype=np.uint8)
+                        out[f"gop.pair{i}.filelen.{name}"] = np.array(len(data), np.int64)
+                    out[f"gop.pair{i}.meta"] = np.array([stage_idx, i_ref, i_cur], np.int64)
+                    per_pair.append(None)
+                    trace.clear()
+                    print("pair", i, "stage", stage_idx, "frames", i_ref, i_cur, flush=True)
+                    return
                 for name in sorted(os.listdir(td)):
                     files[name] = np.frombuffer(open(os.path.join(td, name), "rb").read(), dtype=np.uint8)
                 per_pair.append({"stage": stage_idx, "ref": i_ref, "cur": i_cur, "files": files,
@@ -179,13 +195,16 @@ def main():
             out["gop.psnr_yuv"] = np.array([p["yuv"] for p in ps], np.float64)
             out["gop.psnr_y"] = np.array([p["y"] for p in ps], np.float64)
             for i, pp in enumerate(per_pair):
+                if pp is None:
+                    continue
                 for k in ("mv_hat", "H_t", "L_t", "H_tc", "L_tc", "symbols", "indexes", "push_sizes"):
                     out[f"gop.pair{i}.{k}"] = pp[k]
                 out[f"gop.pair{i}.meta"] = np.array([pp["stage"], pp["ref"], pp["cur"]], np.int64)
                 for name, data in pp["files"].items():
                     out[f"gop.pair{i}.file.{name}"] = data
             for i, (ry, rc, _) in enumerate(rec_frames):
-                out[f"gop.rec{i}.y"] = ry.numpy()
+                if per_pair[0] is not None:
+                    out[f"gop.rec{i}.y"] = ry.numpy()
 
         if not args.gop_only:
             # ---- one pair with the real decoder in the loop (skip_decoding=False, pMCTF_L.py:594-612) ------------
@@ -235,9 +254,10 @@ def main():
                 for k in ("bpp_mv_y", "bpp_mv_z", "bpp", "bit_H", "me_mse", "mv_hat", "H_t"):
                     out[f"ds2.est.{k}"] = np.asarray(e[k].detach().numpy()).copy()
 
-    path = os.path.join(args.out, f"reference_{W}x{H}.npz")
+    suffix = "" if (args.gop == 4 and args.me_stages == 1) else f"_gop{args.gop}_me{args.me_stages}"
+    path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
     np.savez_compressed(path, **out)
-    json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}.meta.json"), "w"), indent=1)
+    json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}{suffix}.meta.json"), "w"), indent=1)
     print("wrote", path, os.path.getsize(path) / 1e6, "MB;", len(out), "arrays")
     print("bits", out["gop.bits"], "psnr", out["gop.psnr_yuv"])
 
