@@ -178,6 +178,19 @@ def main():
             "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
             "host": dict(net.engine().stats),
         }
+        # "+ bpp/PSNR parity vs CPU ref" of BASELINE's metric: rank 0 codes exactly the sequence the real reference was
+        # run on (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4); compare with
+        # the digests of that run (data, tests/golden/).
+        fix = os.path.join(ROOT, "tests", "golden", f"reference_{W}x{H}_gop{args.gop}_me{net.num_me_stages}_digest.npz")
+        if args.q_index == 3 and os.path.exists(fix):
+            import numpy as np
+            g = np.load(fix)
+            out["parity_vs_reference_cpu"] = {
+                "bits_per_frame_identical": enc["bits"] == g["gop.bits"].tolist(),
+                "bpp_reference": float(g["gop.bits"].sum()) / (args.gop * W * H),
+                "psnr_yuv_reference": float(g["gop.psnr_yuv"].mean()),
+                "psnr_max_abs_err_db": float(max(abs(p["yuv"] - r) for p, r in zip(ps, g["gop.psnr_yuv"].tolist()))),
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.gop)
         print(json.dumps(out))
