@@ -171,6 +171,19 @@ class pMCTF(nn.Module):
         return out
 
     @torch.no_grad()
+    def advance_dpb(self, ref_frame, cur_frame, dpb, stage_idx=0, q_index=0, me_downsample=1):
+        """The motion part of encode_one_stage only (pMCTF_L.py:448-495): returns the `dpb` the NEXT pair of the stage
+        needs.  Used by pair-level sharding (pmctf_dist.encode_gop_pair_sharded): the context chain of the motion codec
+        is the only dependency between the pairs of a stage, and a rank re-computes it rather than waiting for it."""
+        self._check_ds(me_downsample)
+        eng = self.engine()
+        dev = next(self.parameters()).device
+        c = lambda t: t.to(dev).contiguous()
+        mv = eng.compress_mv(c(ref_frame[0]), c(cur_frame[0]), dpb, stage_idx=stage_idx, q_index=q_index,
+                             me_downsample=me_downsample)
+        return {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
+
+    @torch.no_grad()
     def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):
         """Estimate-mode stage (pMCTF_L.py:332-379): the same networks as encode_one_stage with Laplace / factorized
         bit estimates instead of range coding.  ref_frame / cur_frame are (N,1,H,W) planes (Y, or UV with the luma

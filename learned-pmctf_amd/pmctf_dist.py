@@ -24,3 +24,108 @@ def gather_gop_metrics(local, n_gops, gop, dist=None, device="cpu"):
         dist.all_reduce(bits, op=dist.ReduceOp.SUM)
         dist.all_reduce(psnr, op=dist.ReduceOp.SUM)
     return bits, psnr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Pair-level sharding inside ONE GOP (the layout of BASELINE configs[4]): stage s has GOP/2^(s+1) independent pairs;
+# pair k of the stage goes to rank k % world.  The only dependency between pairs of a stage is the motion codec's
+# context (`dpb`), a sequential chain pair k-1 -> pair k; it is 7 % of a pair's work, so every rank advances the chain
+# itself up to its own pair (`codec.advance_dpb`, motion only) instead of waiting for a relay, and the one collective of
+# the stage is the all-gather of what the next stage and the decoder need: L, H (luma, chroma) and the motion field of
+# every pair, plus four scalars.  Results are identical to pmctf_gop.encode_gop on one device.
+def pair_owner(pair_idx, world):
+    return pair_idx % world
+
+
+def _gather_stage(local, n_pairs, rank, world, dist, device):
+    """local: {pair_idx: {"t": [tensors...], "s": [floats...]}} for the pairs this rank coded.
+    Returns the same dict for ALL pairs on every rank (tensors on `device`)."""
+    if dist is None or world == 1:
+        return local
+    per_rank = (n_pairs + world - 1) // world
+    ref = next(iter(local.values())) if local else None
+    # shapes are the same on every rank; ranks without a pair learn them from rank 0 (which always owns pair 0)
+    meta = [None]
+    if rank == 0:
+        meta = [([tuple(t.shape) for t in ref["t"]], len(ref["s"]))]
+    dist.broadcast_object_list(meta, src=0)
+    shapes, n_scalars = meta[0]
+    backend_dev = device if dist.get_backend() == "nccl" else "cpu"
+    out = {}
+    slots = [None] * len(shapes)
+    for ti, shp in enumerate(shapes):
+        buf = torch.zeros((per_rank,) + shp, dtype=torch.float32, device=backend_dev)
+        for p, rec in local.items():
+            buf[p // world] = rec["t"][ti].to(backend_dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        slots[ti] = parts
+    sc = torch.zeros(per_rank, max(n_scalars, 1), dtype=torch.float64, device=backend_dev)
+    for p, rec in local.items():
+        sc[p // world, :n_scalars] = torch.tensor(rec["s"], dtype=torch.float64)
+    sc_all = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(sc_all, sc)
+    for p in range(n_pairs):
+        r, j = p % world, p // world
+        out[p] = {"t": [slots[ti][r][j].to(device) for ti in range(len(shapes))],
+                  "s": sc_all[r][j, :n_scalars].tolist()}
+    return out
+
+
+def encode_gop_pair_sharded(codec, frames, pic_height, pic_width, q_index, bin_folder, rank=0, world=1, dist=None,
+                            psize=128):
+    """Same schedule and same return value as pmctf_gop.encode_gop (bits, bits_mv, frames_coded; `results` holds only
+    this rank's pairs), with the pairs of every stage spread over the ranks.  Every rank ends up with the complete
+    subband tree (frames_coded), so any of them can run pmctf_gop.decode_gop."""
+    import math
+    import os
+    gop = len(frames)
+    stages = int(round(math.log2(gop)))
+    assert 2 ** stages == gop and gop >= 2
+    device = frames[0][0].device
+    frames_coded = [None] * gop
+    bits = [None] * gop
+    bits_mv = [None] * gop
+    results = []
+    num_frames = gop
+    for stage_idx in range(stages):
+        num_frames //= 2
+        step = 2 ** stage_idx
+        code_lt = (stage_idx + 1) == stages
+        me_num = min(codec.num_me_stages - 1, stage_idx)
+        dpb = {"mv_feature": None, "ref_mv_y": None}
+        mine = [p for p in range(num_frames) if pair_owner(p, world) == rank]
+        local = {}
+        for p in range((mine[-1] + 1) if mine else 0):
+            i_ref = p * 2 * step
+            i_cur = i_ref + step
+            if stage_idx == 0:
+                (y_ref, c_ref), (y_cur, c_cur) = frames[i_ref], frames[i_cur]
+            else:
+                y_ref, c_ref, _ = frames_coded[i_ref]
+                y_cur, c_cur, _ = frames_coded[i_cur]
+            if p not in mine:        # another rank's pair: only advance the motion codec's context
+                dpb = codec.advance_dpb([y_ref, c_ref], [y_cur, c_cur], dpb, stage_idx=me_num, q_index=q_index)
+                continue
+            r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur],
+                                       output_path=os.path.join(bin_folder, f"{i_cur}.bin"), pic_height=pic_height,
+                                       pic_width=pic_width, stage_idx=me_num, code_lt=code_lt, psize=psize,
+                                       skip_decoding=True, dpb=dpb, q_index=q_index)
+            dpb = r["dpb"]
+            results.append(r)
+            local[p] = {"t": [r["L_t"], r["L_tc"], r["H_t"], r["H_tc"], r["mv_hat"]],
+                        "s": [float(r["bit_H"]), float(r["bit_ME"]), float(r["bit_L"]) if code_lt else 0.0]}
+        everything = _gather_stage(local, num_frames, rank, world, dist, device)
+        for p in range(num_frames):
+            i_ref = p * 2 * step
+            i_cur = i_ref + step
+            L_t, L_tc, H_t, H_tc, mv_hat = everything[p]["t"]
+            bit_H, bit_ME, bit_L = everything[p]["s"]
+            frames_coded[i_ref] = [L_t, L_tc, None]
+            frames_coded[i_cur] = [H_t, H_tc, mv_hat]
+            bits[i_cur] = bit_H + bit_ME
+            bits_mv[i_cur] = bit_ME
+            if code_lt:
+                bits[i_ref] = bit_L
+                bits_mv[i_ref] = 0.0
+    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}

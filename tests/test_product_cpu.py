@@ -244,3 +244,68 @@ def test_bitstream_inspector_reads_reference_files():
                              capture_output=True, text=True, check=True).stdout
     assert "image file: 128x128 (Y)" in out and "image file: 64x64 (UV)" in out and "motion file: mv_y_q_index 0" in out
     assert out.count("1 part(s)") == 4 and "(!)" not in out
+
+
+class _ChainCodec:
+    """A cheap deterministic stand-in with the codec API of pmctf_gop / pmctf_dist: its outputs depend on the inputs AND
+    on the motion-context chain, so a wrong schedule, a broken chain or a mis-gathered tensor changes the result."""
+    num_me_stages = 4
+
+    @staticmethod
+    def _chain(ref, cur, dpb, stage_idx, q_index):
+        prev = 0.0 if dpb["mv_feature"] is None else float(dpb["mv_feature"].reshape(-1)[0])
+        v = 0.5 * prev + float((cur[0] - ref[0]).mean()) + 0.01 * stage_idx + 0.001 * q_index
+        return {"mv_feature": torch.full((1, 2, 2, 2), v), "ref_mv_y": torch.full((1, 1, 1, 1), v * 2)}, v
+
+    def advance_dpb(self, ref_frame, cur_frame, dpb, stage_idx=0, q_index=0):
+        return self._chain(ref_frame, cur_frame, dpb, stage_idx, q_index)[0]
+
+    def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
+                         psize=128, skip_decoding=True, stage_idx=0, q_index=0):
+        new, v = self._chain(ref_frame, cur_frame, dpb, stage_idx, q_index)
+        (ry, rc), (cy, cc) = ref_frame, cur_frame
+        return {"L_t": (ry + cy) / 2 + v, "L_tc": (rc + cc) / 2 - v, "H_t": cy - ry + v, "H_tc": cc - rc + 2 * v,
+                "mv_hat": torch.full((1, 2) + tuple(ry.shape[2:]), v), "dpb": new,
+                "bit_H": 1000.0 + round(v * 1e6), "bit_ME": 10.0 + stage_idx, "bit_L": 77.0 if code_lt else None}
+
+
+def _pair_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import pmctf_dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    frames = [[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_dist.encode_gop_pair_sharded(_ChainCodec(), frames, 8, 12, 3, td, rank, world, dist)
+    q.put((rank, enc["bits"], enc["bits_mv"], [[t if t is None else t.numpy() for t in fc] for fc in enc["frames_coded"]],
+           len(enc["results"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pair_sharding_inside_a_gop_gloo(world):
+    """BASELINE configs[4] layout: the pairs of every temporal stage spread over the ranks, one all-gather per stage.
+    Every rank must end with exactly the subband tree and bit counts of the single-process schedule."""
+    import torch.multiprocessing as mp
+    import pmctf_gop
+    g = torch.Generator().manual_seed(5)
+    frames = [[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
+    with tempfile.TemporaryDirectory() as td:
+        ref = pmctf_gop.encode_gop(_ChainCodec(), frames, 8, 12, 3, td)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_pair_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sum(r[4] for r in res) == 15                       # 8 + 4 + 2 + 1 pairs, each coded exactly once
+    for rank, bits, bits_mv, fc, _ in res:
+        assert bits == ref["bits"] and bits_mv == ref["bits_mv"], rank
+        for a, b in zip(fc, ref["frames_coded"]):
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or np.array_equal(x, y.numpy()), rank

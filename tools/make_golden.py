@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--gop_only", action="store_true", help="only the GOP harness loop (files, bits, PSNR)")
     ap.add_argument("--gop", type=int, default=4, help="GOP size of the harness loop")
     ap.add_argument("--me_stages", type=int, default=1, help="num_me_stages of the model")
+    ap.add_argument("--q_index", type=int, default=3, help="rate point of the GOP harness loop")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -187,7 +188,7 @@ def main():
                 trace.clear()
 
             trace.clear()
-            enc = pmctf_gop.encode_gop(net, frames, H, W, q_index=3, bin_folder=td, on_pair=on_pair)
+            enc = pmctf_gop.encode_gop(net, frames, H, W, q_index=args.q_index, bin_folder=td, on_pair=on_pair)
             rec_frames = pmctf_gop.decode_gop(net, enc["frames_coded"])
             ps = pmctf_gop.gop_psnr(rec_frames, frames, H, W)
             out["gop.bits"] = np.array(enc["bits"], np.float64)
@@ -255,6 +256,8 @@ def main():
                     out[f"ds2.est.{k}"] = np.asarray(e[k].detach().numpy()).copy()
 
     suffix = "" if (args.gop == 4 and args.me_stages == 1) else f"_gop{args.gop}_me{args.me_stages}"
+    if args.q_index != 3:
+        suffix += f"_q{args.q_index}"
     path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}{suffix}.meta.json"), "w"), indent=1)
