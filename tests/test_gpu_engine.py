@@ -514,8 +514,8 @@ def test_headline_config_1080p_gop16_vs_reference(cuda, q_index):
         # symbol, the bytes inside differ (13 of 47 files on this sequence) — reported above, and bounded here
         assert same + diff == 47 and same >= 30
     else:
-        # ends of the RD sweep: the same effect can move a stream by one 32-bit rANS word (observed: q_index 20, one frame
-        # of 16 is 32 bits longer out of 98.5 Mbit, PSNR off by 1.3e-4 dB).  Stated as measured, bounded here.
+        # ends of the RD sweep: the same effect can move a stream by one 32-bit rANS word (observed: q_index 20, two frames
+        # of 16 are 32 bits longer out of 98.5 Mbit, PSNR off by 1.3e-4 dB).  Stated as measured, bounded here.
         dbits = np.abs(np.array(enc["bits"]) - g["gop.bits"])
         print("   per-frame bit differences:", dbits.tolist())
         assert dbits.max() <= 64 and dbits.sum() <= 1e-6 * g["gop.bits"].sum()
