@@ -63,3 +63,21 @@ def yuv_420_to_444(yuv, mode="bilinear", return_tuple=False):
     if return_tuple:
         return y, u, v
     return torch.cat((y, u, v), dim=1)
+
+
+def normalize_tensor(im, im_name="lh"):
+    """Map a tensor into [-1, 1] for debug plots (pMCTF/utils/util.py:327-348; used by test_pMCTF_CA.py:97).
+    Approximation subbands / images ('ll', 'x', 'x_hat') are stretched to the full range when they exceed it; detail
+    subbands keep zero at zero: the larger-magnitude end goes to 1 (flipping the sign when that end is negative)."""
+    lo, hi = torch.min(im), torch.max(im)
+    if im_name in ("ll", "x", "x_hat"):
+        out_lo, out_hi = -1.0, 1.0
+    else:
+        if torch.abs(hi) <= torch.abs(lo):
+            im = -im
+            lo, hi = torch.min(im), torch.max(im)
+        out_hi = 1.0
+        out_lo = torch.sign(lo) * torch.abs(lo) / torch.abs(hi)
+    if hi > 1 or lo < -1:
+        im = (out_hi - out_lo) * (im - lo) / (hi - lo) + out_lo
+    return im
