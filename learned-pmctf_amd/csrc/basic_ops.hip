@@ -105,36 +105,40 @@ __global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const floa
 }
 
 
-// 3x3, stride 1, pad 1, Cin <= 3, many couts (1->64/112/128, 2->112): a WAVE owns a strip of 16 consecutive output
-// pixels of one row and up to 64 couts (lane = cout).  All lanes of the wave read the same input taps, so the 3x18xCIN
-// input window is fetched with wave-uniform (scalar) loads once per strip and every output costs 9*CIN FMAs plus one
-// coalesced store — no per-output index arithmetic.  Same sum order: acc = bias; for ky: for kx: for ci: fmaf.
+// 3x3, stride 1, pad 1, Cin <= 3, many couts (1->64/112/128, 2->112), Cout % 4 == 0: a lane owns FOUR consecutive
+// couts (Q = Cout/4 lanes per pixel) of a strip of 8 consecutive output pixels; the G = 64/Q lane groups of a wave take
+// adjacent strips, so the wave writes one contiguous run of G*8 pixels x Cout floats with 16-byte stores (whole cache
+// lines; the layer is write-bound: 4*Cout bytes out per 4*Cin bytes in).  The 3x10xCIN input window is read once per
+// strip (same address for the Q lanes of a group), no per-output index arithmetic.
+// Same sum order: acc = bias; for ky: for kx: for ci: fmaf.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ w,
                                                                      const float *__restrict__ bias, const float *res1,
                                                                      const float *res2, float *y, int N, int H, int W,
-                                                                     int Cout, int act, float slope, int cgroups,
-                                                                     int strips_per_row, long total_strips) {
-    constexpr int P = 16;
+                                                                     int Cout, int act, float slope, int Q, int G,
+                                                                     int wstrips_per_row, long total_items) {
+    constexpr int P = 8;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cg = wave % cgroups;                       // cgroups in {1,2,4}
-    const int spb = 4 / cgroups;                         // strips per block and pass
-    const int co = cg * 64 + lane;
-    const bool active = co < Cout;
-    const int cw = active ? co : 0;
-    float wr[9 * CIN];
+    const int wave = threadIdx.x >> 6;
+    const int q = lane % Q, g = lane / Q;
+    const bool active = g < G;
+    const int co = 4 * q;
+    float4 wr[9 * CIN];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(cw * CIN + ci) * 9 + t];
-    const float b = bias ? bias[cw] : 0.0f;
-    for (long strip = (long)blockIdx.x * spb + wave / cgroups; strip < total_strips; strip += (long)gridDim.x * spb) {
-        const int sx = (int)(strip % strips_per_row) * P;
-        const long r = strip / strips_per_row;
+        for (int ci = 0; ci < CIN; ++ci)
+            wr[t * CIN + ci] = make_float4(w[((co + 0) * CIN + ci) * 9 + t], w[((co + 1) * CIN + ci) * 9 + t],
+                                           w[((co + 2) * CIN + ci) * 9 + t], w[((co + 3) * CIN + ci) * 9 + t]);
+    const float4 b = bias ? *(const float4 *)(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long item = (long)blockIdx.x * 4 + wave; item < total_items; item += (long)gridDim.x * 4) {
+        const int ws = (int)(item % wstrips_per_row);
+        const long r = item / wstrips_per_row;
         const int oy = (int)(r % H);
         const int n = (int)(r / H);
+        const int sx = (ws * G + g) * P;
+        if (!active || sx >= W) continue;
         float in[3][P + 2][CIN];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -149,24 +153,30 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
                 for (int ci = 0; ci < CIN; ++ci) in[ky][j][ci] = ok ? xr[(size_t)ix * CIN + ci] : 0.0f;
             }
         }
-        if (!active) continue;
         const size_t obase = (((size_t)n * H + oy) * W + sx) * Cout + co;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             if (sx + j < W) {
-                float acc = b;
+                float4 acc = b;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int ci = 0; ci < CIN; ++ci)
-                            acc = __builtin_fmaf(in[ky][j + kx][ci], wr[(ky * 3 + kx) * CIN + ci], acc);
-                float v = pm::apply_act(acc, act, slope);
-                const size_t o = obase + (size_t)j * Cout;
-                if (res1) v = v + res1[o];
-                if (res2) v = v + res2[o];
-                y[o] = v;
+                        for (int ci = 0; ci < CIN; ++ci) {
+                            const float v = in[ky][j + kx][ci];
+                            const float4 wt = wr[(ky * 3 + kx) * CIN + ci];
+                            acc.x = __builtin_fmaf(v, wt.x, acc.x);
+                            acc.y = __builtin_fmaf(v, wt.y, acc.y);
+                            acc.z = __builtin_fmaf(v, wt.z, acc.z);
+                            acc.w = __builtin_fmaf(v, wt.w, acc.w);
+                        }
+                float4 o = make_float4(pm::apply_act(acc.x, act, slope), pm::apply_act(acc.y, act, slope),
+                                       pm::apply_act(acc.z, act, slope), pm::apply_act(acc.w, act, slope));
+                const size_t oi = obase + (size_t)j * Cout;
+                if (res1) { const float4 r1 = *(const float4 *)(res1 + oi); o.x = o.x + r1.x; o.y = o.y + r1.y; o.z = o.z + r1.z; o.w = o.w + r1.w; }
+                if (res2) { const float4 r2 = *(const float4 *)(res2 + oi); o.x = o.x + r2.x; o.y = o.y + r2.y; o.z = o.z + r2.z; o.w = o.w + r2.w; }
+                *(float4 *)(y + oi) = o;
             }
         }
     }
@@ -472,18 +482,18 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         return PMCTF_EINVAL;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
-    if (KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 48 && Cout <= 256) {
-        const int cg0 = (Cout + 63) / 64, cgroups = cg0 == 3 ? 4 : cg0;
-        const int strips_per_row = (W + 15) / 16;
-        const long total_strips = (long)N * H * strips_per_row;
-        const int spb = 4 / cgroups;
-        long nb = (total_strips + spb - 1) / spb;
-        if (nb > 8192) nb = 8192;
+    if (KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 32 && Cout <= 256 &&
+        (Cout & 3) == 0) {
+        const int Q = Cout / 4, G = 64 / Q;                    // lanes per pixel, strips per wave
+        const int wstrips_per_row = (W + G * 8 - 1) / (G * 8);
+        const long total_items = (long)N * H * wstrips_per_row;
+        long nb = (total_items + 3) / 4;
+        if (nb > 16384) nb = 16384;
         dim3 grid((unsigned)nb), block(256);
         hipStream_t st = (hipStream_t)stream;
 #define PM_STRIP(C_)                                                                                                 \
     PM_LAUNCH((conv3x3_smallcin_strip_kernel<C_>), grid, block, 0, st, x, w, bias, res1, res2, y, N, H, W, Cout, act,  \
-              slope, cgroups, strips_per_row, total_strips);                                                         \
+              slope, Q, G, wstrips_per_row, total_items);                                                            \
     return launch_ok();
         if (Cin == 1) { PM_STRIP(1) }
         if (Cin == 2) { PM_STRIP(2) }
