@@ -30,6 +30,11 @@ def report(name, nbytes, t):
 
 def main():
     dev = "cuda"
+    big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)      # 1 GiB
+    dst = torch.empty_like(big)
+    report("reference point: device-to-device copy of 1 GiB (runtime's copy kernel)", 2 * big.numel() * 4,
+           timed(lambda: dst.copy_(big), 5))
+    del big, dst
     H, W = 1152, 1920
     f4 = 4
     y = torch.randn(1, 1, H, W, device=dev)
