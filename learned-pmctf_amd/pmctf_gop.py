@@ -19,10 +19,18 @@ def psnr(a, b):
     return (20 * torch.log10(255.0 / torch.sqrt(mse))).item()
 
 
+def ca_psize(me_downsample):
+    """padding granularity the content-adaptive harness uses for a motion down-sampling factor (test_pMCTF_CA.py:121-123)"""
+    psize = 256 if me_downsample > 2 else 128
+    return psize * 2 if me_downsample > 4 else psize
+
+
 def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_decoding=True, psize=128,
-               on_pair=None):
+               on_pair=None, me_downsample=1):
     """frames: list (len = GOP size, power of two) of [Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] padded tensors.
-    Returns dict(bits[], frames_coded (after forward), results[] per pair in coding order)."""
+    Returns dict(bits[], frames_coded (after forward), results[] per pair in coding order).
+    me_downsample > 1: the schedule of test_pMCTF_CA.py:code_one_gop (motion at reduced resolution; pad the frames to
+    ca_psize(me_downsample) and pass that as psize)."""
     gop = len(frames)
     stages = int(round(math.log2(gop)))
     assert 2 ** stages == gop and gop >= 2
@@ -51,7 +59,7 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
             r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur], output_path=bin_path,
                                        pic_height=pic_height, pic_width=pic_width, stage_idx=me_num,
                                        code_lt=code_lt, psize=psize, skip_decoding=skip_decoding, dpb=dpb,
-                                       q_index=q_index)
+                                       q_index=q_index, **({"me_downsample": me_downsample} if me_downsample != 1 else {}))
             frames_coded[i_ref] = [r["L_t"], r["L_tc"], None]
             frames_coded[i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
             dpb = r["dpb"]

@@ -521,3 +521,25 @@ def test_headline_config_1080p_gop16_vs_reference(cuda, q_index):
         assert dbits.max() <= 64 and dbits.sum() <= 1e-6 * g["gop.bits"].sum()
         assert psnr_err < 5e-4
         assert same + diff == 47
+
+
+def test_gop_with_reduced_resolution_motion(setup):
+    """The content-adaptive harness's GOP schedule (test_pMCTF_CA.py:code_one_gop) with me_downsample=2: a GOP of 4
+    through the same loop on the product and on the oracle — identical bits, files and reconstruction."""
+    import pmctf_gop
+    net, orc = setup
+    fr = frames(W, H, 4, seed=9)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    assert pmctf_gop.ca_psize(2) == 128 and pmctf_gop.ca_psize(4) == 256 and pmctf_gop.ca_psize(8) == 512
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_gop.encode_gop(net, frd, H, W, 3, td, me_downsample=2)
+        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+    with tempfile.TemporaryDirectory() as td:
+        oenc = pmctf_gop.encode_gop(orc, fr, H, W, 3, td, me_downsample=2)
+        orec = pmctf_gop.decode_gop(orc, oenc["frames_coded"])
+    assert enc["bits"] == oenc["bits"] and enc["bits_mv"] == oenc["bits_mv"]
+    for r, o in zip(enc["results"], oenc["results"]):
+        for k in o["files"]:
+            assert r["files"][k] == o["files"][k], k
+    for (ry, rc, _), (oy, oc, _) in zip(rec, orec):
+        assert_same(ry, oy, "reconstructed luma"); assert_same(rc, oc, "reconstructed chroma")
