@@ -76,8 +76,10 @@ int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *w_packed, const floa
                                int stride, int pad_top, int pad_left, int Ho, int Wo, int act, float slope,
                                void *stream);
 
-/* Same contract for Cin <= 4 (any Cin >= 1), plain OIHW weights on the device: direct
- * convolution on the vector ALU (first layers: 1->16, 1->64, 1->112, 1->128, 2->112, 2->64 ...). */
+/* Same contract for Cin <= 4 (any Cin >= 1), plain OIHW weights on the device: direct convolution on the vector ALU
+ * (first layers: PredictUpdate conv1 1->16 lifting_1d.py:38; PostProcess conv1 1->64 postprocessing.py:35; four-step
+ * y_spatial_prior_k.0 1->112 and conv1_context 1|2->112 context_fusion_4step.py:48,63,73,83; masked 1->128
+ * context_fusion.py:79; MV encoder first conv 2->64 video_net.py:128). */
 int pmctf_conv2d_smallcin_f32(const float *x, const float *w_oihw, const float *bias,
                               const float *res1, const float *res2, float *y,
                               int N, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -168,19 +170,29 @@ int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, fl
 /* ---- quantisation + symbol hand-off --------------------------------
  * sym/idx receive one full-size push (int16 symbol, int16 CDF row) in the reference's flattening order
  * (NCHW), exactly what EntropyCoder.encode_with_indexes is given (entropy_models.py:37-40,269-278). */
-/* params: NHWC [N,H,W,2] (params_sub = 0) or, for params computed only at the class-k positions, [N,H/2,W/2,2]
- * (params_sub = 1; H and W even). */
+/* One step of ContextFusionFourStep.forward(write=True): process_with_mask + build_indexes for parity class k
+ * (context_fusion_4step.py:127-137,156-189); x, so_far planes [N,1,H,W].
+ * params: NHWC [N,H,W,2] (scale, mean) (params_sub = 0) or, for params computed only at the class-k positions,
+ * [N,H/2,W/2,2] (params_sub = 1; H and W even). */
 int pmctf_fourstep_quant_f32(const float *x, const float *params, float *so_far, int16_t *sym, int16_t *idx, int N,
                              int H, int W, int k, int params_sub, float log_scale_min, float log_scale_step,
                              void *stream);
-/* planes > 0: push in the order of the sequential coder (_compress_subband_ar, pWave.py:531-555): position-major,
+/* LL subband, one-shot path of pWave.compress (pWave.py:408-418; CompressionModel.process gaussian_model.py:59-63):
+ * ll_hat = round(round(round(ll) - mean) + mean), symbol round(round(ll) - mean), CDF row of scale.
+ * planes > 0: push in the order of the sequential coder (_compress_subband_ar, pWave.py:531-555): position-major,
  * plane-minor (total = planes * positions); planes = 0: plane-major NCHW order of the one-shot path (pWave.py:418). */
 int pmctf_ll_quant_f32(const float *ll, const float *params, float *ll_hat, int16_t *sym, int16_t *idx, int64_t total,
                        int planes, float log_scale_min, float log_scale_step, void *stream);
+/* MV hyper latent (pMCTF_L.py:463-464,478): z_hat = round(z) (NHWC [HW][C]); symbols [C][HW] with CDF row = channel
+ * (BitEstimator.build_indexes / encode, entropy_models.py:181-195) */
 int pmctf_z_symbols_f32(const float *z, float *z_hat, int16_t *sym, int16_t *idx, int HW, int C, void *stream);
+/* step t of MVCoderQuad.forward_four_part_prior(write=True) (four_part_prior.py:89-208): y [HW][64], common [HW][192]
+ * (quant step | scales | means, LowerBound 0.5 on the step), sp [HW][128] spatial-prior output (t > 0); writes the
+ * step's y_hat contribution into so_far [HW][64] and the 16-channel symbol/row planes [16][HW] */
 int pmctf_mv_fourpart_step_f32(const float *y, const float *common, const float *sp, float *so_far, int16_t *sym,
                                int16_t *idx, int H, int W, int t, float log_scale_min, float log_scale_step,
                                void *stream);
+/* y_hat = so_far * q_dec with q_dec = max(quant step, 0.5) (four_part_prior.py:194-197; video_net.py:14-20) */
 int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat, int64_t HW, void *stream);
 
 /* ---- decoder side ----------------------------------------------------------------
@@ -190,7 +202,9 @@ int pmctf_mv_dequant_f32(const float *so_far, const float *common, float *y_hat,
  *   w_packed: pmctf_ll_ar_pack_weights() output on the device; stream_words: the rANS payload (after the 1-byte
  *   header) as little-endian uint32 on the device; (x0,pos0) / state_out[0..1]: Rans64 state and next-word index
  *   before / after (state_out[2] != 0: stream exhausted); cdf/sizes/offsets: the Laplace tables on the device;
- *   ll_out [N][H][W]; scratch_zeroed: pmctf_ll_ar_scratch_floats(N,H,W) floats, zero-filled.  N <= 2. */
+ *   ll_out [N][H][W]; scratch_zeroed: pmctf_ll_ar_scratch_floats(N,H,W) floats, zero-filled.  N <= 4
+ *   planes per stream (Y 1, UV 2, RGB 3).  pack_weights takes the masked weights of maskedConv1 (w_a,b_a), the five
+ *   type-B layers residualBlocks.{0,1}.conv{1,2} + maskedConv2 (w_b,b_b) and convs.{0,1,2} (context_fusion.py:79-135). */
 int64_t pmctf_ll_ar_packed_size(void);
 int pmctf_ll_ar_pack_weights(const float *w_a, const float *b_a, const float *const *w_b, const float *const *b_b,
                              const float *w_p0, const float *b_p0, const float *w_p1, const float *b_p1,
@@ -235,7 +249,7 @@ int pmctf_z_estimate_f32(const float *z, float *z_hat, const float *consts, int6
 /* step t of MVCoderQuad.forward_four_part_prior (four_part_prior.py:89-195); layouts as pmctf_mv_fourpart_step_f32. */
 int pmctf_mv_fourpart_estimate_f32(const float *y, const float *common, const float *sp, float *so_far, int H, int W,
                                    int t, double *bits, void *stream);
-/* nn.MSELoss numerator: sum += sum((a[i]-b[i])^2) */
+/* nn.MSELoss numerator (pMCTF_L.py:351,373; pWave.py:309): sum += sum((a[i]-b[i])^2) */
 int pmctf_sqdiff_sum_f32(const float *a, const float *b, int64_t n, double *sum, void *stream);
 
 #ifdef __cplusplus
