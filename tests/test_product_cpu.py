@@ -309,3 +309,50 @@ def test_pair_sharding_inside_a_gop_gloo(world):
         for a, b in zip(fc, ref["frames_coded"]):
             for x, y in zip(a, b):
                 assert (x is None and y is None) or np.array_equal(x, y.numpy()), rank
+
+
+def test_range_coder_random_tables_property():
+    """Property test over random CDF tables (ragged row lengths, tiny and huge frequencies) and random symbols, in and out
+    of the table range (bypass digits): the product's host coder writes the oracle's bytes and decodes them back."""
+    from hypothesis import given, settings, strategies as st
+    from pmctf_oracle import clib
+    from pMCTF.entropy_models.entropy_models import EntropyCoder
+
+    @st.composite
+    def case(draw):
+        rows = draw(st.integers(1, 6))
+        cols = draw(st.integers(4, 40))
+        seed = draw(st.integers(0, 2 ** 31 - 1))
+        n = draw(st.integers(0, 400))
+        return rows, cols, seed, n
+
+    @settings(max_examples=60, deadline=None)
+    @given(case())
+    def run(c):
+        rows, cols, seed, n = c
+        r = np.random.default_rng(seed)
+        cdf = np.zeros((rows, cols), np.int32)
+        sizes = np.zeros(rows, np.int32)
+        offs = r.integers(-20, 5, rows).astype(np.int32)
+        for i in range(rows):
+            k = int(r.integers(2, cols))              # number of coded symbols incl. the escape symbol; size = k + 1
+            w = r.random(k) ** 4 + 1e-4               # skewed: some near-minimal frequencies
+            pmf = w / w.sum()
+            q = clib.pmf_to_quantized_cdf(pmf.astype(np.float32).tolist(), 16)
+            cdf[i, :k + 1] = q
+            sizes[i] = k + 1
+        idx = r.integers(0, rows, n).astype(np.int16)
+        span = (sizes[idx] - 2).astype(np.int64)
+        sym = (-offs[idx] + r.integers(-3, 3, n) + (r.random(n) < 0.7) * r.integers(0, 1 << 30, n) % np.maximum(span, 1))
+        far = r.random(n) < 0.05
+        sym = np.where(far, r.integers(-3000, 3000, n), sym).astype(np.int16)
+        ec = EntropyCoder(False, 1)
+        ec.reset(); ec.encode_with_indexes(sym, idx, cdf, sizes, offs); ec.flush()
+        s = ec.get_encoded_stream()
+        o = clib.RansEncoder(); o.reset(); o.encode_with_indexes(sym, idx, cdf, sizes, offs); o.flush()
+        assert o.get_encoded_stream().tobytes() == s
+        ec.set_stream(s)
+        out = ec.decode_stream(torch.from_numpy(idx), cdf, sizes, offs).numpy().astype(np.int16)
+        assert np.array_equal(out, sym)
+
+    run()
