@@ -48,18 +48,20 @@ def get_rounded_q(q_scale):
 class SymbolStream:
     """Device-side int16 (symbol, CDF row) buffers of one bitstream, filled push by push in coding order."""
 
-    def __init__(self, total, device):
+    def __init__(self, total, device, merge=True):
         self.sym = torch.empty(total, dtype=torch.int16, device=device)
         self.idx = torch.empty(total, dtype=torch.int16, device=device)
         self.off = 0
         self.total = total
         self.segments = []          # (offset, count, table_name)
+        self.merge = merge          # False: keep one segment per push (needed to slice a batched stream per plane)
 
     def take(self, n, table):
         off = self.off
         assert off + n <= self.total, "symbol stream overflow"
         self.off += n
-        if self.segments and self.segments[-1][2] == table and self.segments[-1][0] + self.segments[-1][1] == off:
+        if self.merge and self.segments and self.segments[-1][2] == table and \
+                self.segments[-1][0] + self.segments[-1][1] == off:
             o, c, t = self.segments[-1]
             self.segments[-1] = (o, c + n, t)
         else:
@@ -128,11 +130,30 @@ class RangeCoderPool:
             buf = np.empty(n, np.uint8)
             _lib.check(R.pmctf_rans_encoder_get_encoded_stream(enc, buf.ctypes.data, n), "rans get stream")
             data = hdr + buf.tobytes()
-        return size, data, (s_np, i_np) if keep else None
+        if keep:      # the symbols / CDF rows of exactly this bitstream, in coding order
+            trace = (np.concatenate([s_np[o:o + c] for o, c, _ in segments]) if segments else s_np[:0],
+                     np.concatenate([i_np[o:o + c] for o, c, _ in segments]) if segments else i_np[:0])
+            return size, data, trace
+        return size, data, None
 
     def submit(self, stream, tables, header, path, keep=False):
         hs, hi, ev = stream.to_host()
         return self.pool.submit(self._run, hs, hi, ev, list(stream.segments), tables, header, path, keep)
+
+    def submit_planes(self, stream, nplanes, groups, tables, keep=False):
+        """One device stream holds the symbols of `nplanes` independently coded planes (every push is plane-major, as
+        the reference flattens NCHW).  groups: [(first_plane, n_planes, header_fn, path)] -> one bitstream per group,
+        made of that group's slice of every push.  One D2H copy serves all groups.  Returns a list of futures."""
+        hs, hi, ev = stream.to_host()
+        futures = []
+        for lo, cnt_planes, header, path in groups:
+            segs = []
+            for off, cnt, tname in stream.segments:
+                assert cnt % nplanes == 0
+                per = cnt // nplanes
+                segs.append((off + lo * per, cnt_planes * per, tname))
+            futures.append(self.pool.submit(self._run, hs, hi, ev, segs, tables, header, path, keep))
+        return futures
 
 
 class HipEngine:
@@ -615,11 +636,14 @@ class HipEngine:
         ops.sqdiff_sum(x.contiguous(), x_hat, sq)
         return {"x_hat": x_hat, "subbands": hat, "bits": sink.bits, "sq_err": sq}
 
-    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False, estimate=False, defer=False):
+    def pwave_compress(self, coder, x, q_index, qp_scale=None, ar_order=False, estimate=False, defer=False,
+                       per_push=False):
         """x: plane (N,1,H,W).  Returns (x_hat plane, SymbolStream).  ar_order: LL symbols in the sequential coder's
         order (needed for streams the decoder will read: skip_decoding=False, pWave.py:410-411,531-555).
         estimate=True: returns (x_hat, BitSink, quantised subbands) — see pwave_forward.
-        defer=True: returns (synthesis, SymbolStream); synthesis() computes x_hat later."""
+        defer=True: returns (synthesis, SymbolStream); synthesis() computes x_hat later.
+        per_push=True: the stream keeps one segment per push, so a batch of independently coded planes can be cut into
+        one bitstream per plane group (RangeCoderPool.submit_planes)."""
         q_scale, q_scale_ll = self.q_scales(coder, q_index, qp_scale)
         N, _, H, W = x.shape
         clip = 8192.0
@@ -628,7 +652,8 @@ class HipEngine:
         for lvl in range(self.L):
             y[lvl] = self.forward_lift_2d(coder, ll)
             ll = y[lvl]["ll"]
-        stream = BitSink(N, self.dev) if estimate else SymbolStream(self.pwave_symbol_count(N, H, W), self.dev)
+        stream = BitSink(N, self.dev) if estimate else SymbolStream(self.pwave_symbol_count(N, H, W), self.dev,
+                                                                    merge=not per_push)
         hat = {lvl: {} for lvl in range(self.L)}
         llq = ew(EW_ROUND_CLAMP_MULS, ll, alpha=q_scale_ll, beta=clip)
         params = self.context_fusion_ll(coder, llq)
@@ -730,6 +755,40 @@ class HipEngine:
             return out
         return finish()
 
+
+    def compress_stage_batched(self, refs, curs, code_lt, mv_hats, ischroma, stage_idx=0, q_index=0, on_stream=None):
+        """compress_one_stage for ALL pairs of a temporal stage at once: the pairs are independent (same coder weights,
+        per-plane contexts), so they run as one batch — every kernel launch covers len(refs) x more pixels, which is
+        what the latency-bound small subbands need.  refs/curs: per pair a (n,1,H,W) plane tensor (n = 1 luma,
+        2 chroma); mv_hats: per pair (1,2,H,W) at luma resolution.  on_stream(kind, SymbolStream, planes_per_pair).
+        Per plane the arithmetic is exactly that of compress_one_stage.  Returns dict with batched tensors + finish()."""
+        n = refs[0].shape[0]
+        ref = torch.cat(refs, dim=0)
+        cur = torch.cat(curs, dim=0)
+        flows = []
+        for mv in mv_hats:
+            f = ops.bilinear_down2(mv, 2.0) if ischroma else mv
+            flows.extend([f] * n)
+        mv_all = torch.cat(flows, dim=0)
+        L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_all, stage_idx)
+        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+        H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, False, defer=True, per_push=True)
+        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "L_t_hat": None}
+        if on_stream is not None:
+            on_stream("H", h_stream, n)
+        L_syn = None
+        if code_lt:
+            L_syn, l_stream = self.pwave_compress("lp_coder", L_t, q_index, None, False, defer=True, per_push=True)
+            if on_stream is not None:
+                on_stream("L", l_stream, n)
+
+        def finish():
+            out["H_t_hat"] = H_syn()
+            if L_syn is not None:
+                out["L_t_hat"] = L_syn()
+            return out
+        out["finish"] = finish
+        return out
 
     # =================================================================================================
     # Decoder (SURVEY §8f rank 1): pMCTF.decompress_mv / pWave.decompress on the GPU, entropy decoding on the host

@@ -171,6 +171,76 @@ class pMCTF(nn.Module):
         return out
 
     @torch.no_grad()
+    def encode_stage_pairs(self, pairs, code_lt, dpb, output_paths, pic_width, pic_height, psize=128, stage_idx=0,
+                           q_index=0):
+        """All pairs of one temporal stage in one call: pairs = [(ref_frame, cur_frame)], output_paths = ["k.bin"].
+        Returns ([result dict per pair, exactly what encode_one_stage(skip_decoding=True) returns for it], dpb for a
+        following call).  The motion codec runs pair after pair (its context is a chain, pMCTF_L.py:448-495); the
+        temporal lifting and the spatial coders — 93 % of the work — run as ONE batch over the pairs, so every launch
+        is len(pairs) times larger (the MI355X-side answer to the small, latency-bound subbands of the wavelet
+        pyramid; 288 GB of HBM hold the larger activations easily).  Files, bits and tensors are identical to calling
+        encode_one_stage pair by pair (tests/test_gpu_engine.py::test_batched_stage_equals_pair_by_pair)."""
+        eng = self.engine()
+        dev = next(self.parameters()).device
+        c = lambda t: t.to(dev).contiguous()
+        start = time.time()
+        keep = eng.keep_streams
+        P = len(pairs)
+        jobs = [dict() for _ in range(P)]
+        mvs = []
+        for i, ((ref_y, _), (cur_y, _)) in enumerate(pairs):
+            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index)
+            jobs[i]["mv"] = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0),
+                                             output_paths[i].replace(".bin", "_mv.bin"), keep)
+            dpb = {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
+            mvs.append((mv, dpb))
+
+        def paths_for(i, kind, chroma):
+            base = osp.basename(output_paths[i])
+            if kind == "H":
+                return output_paths[i].replace(".bin", "_C_main.bin") if chroma else output_paths[i]
+            return output_paths[i].replace(base, "0_C_main.bin" if chroma else "0_main.bin")
+
+        def submitter(chroma):
+            def submit(kind, stream, n):
+                if chroma:
+                    hdr = lambda m: image_header(pic_height // 2, pic_width // 2, 2, m)
+                else:
+                    hdr = lambda m: image_header(pic_height, pic_width, 1, m)
+                groups = [(i * n, n, hdr, paths_for(i, kind, chroma)) for i in range(P)]
+                for i, fut in enumerate(eng.coder.submit_planes(stream, P * n, groups, eng.tables, keep)):
+                    jobs[i][kind + ("c" if chroma else "")] = fut
+            return submit
+
+        mv_hats = [m["mv_hat"] for m, _ in mvs]
+        luma = eng.compress_stage_batched([c(r[0]) for r, _ in pairs], [c(cu[0]) for _, cu in pairs], code_lt, mv_hats,
+                                          False, stage_idx, q_index, on_stream=submitter(False))
+        chroma = eng.compress_stage_batched([c(r[1]) for r, _ in pairs], [c(cu[1]) for _, cu in pairs], code_lt, mv_hats,
+                                            True, stage_idx, q_index, on_stream=submitter(True))
+        luma["finish"]()
+        chroma["finish"]()
+        results = []
+        for i in range(P):
+            done = {k: j.result() for k, j in jobs[i].items()}
+            bits = {k: v[0] * 8.0 for k, v in done.items()}
+            mv, dpb_i = mvs[i]
+            ys, cs = slice(i, i + 1), slice(2 * i, 2 * i + 2)
+            r = {"L_t": (luma["L_t_hat"] if code_lt else luma["L_t"])[ys], "H_t": luma["H_t_hat"][ys],
+                 "L_tc": (chroma["L_t_hat"] if code_lt else chroma["L_t"])[cs], "H_tc": chroma["H_t_hat"][cs],
+                 "bit_H": bits["H"] + bits["Hc"], "bit_L": bits["L"] + bits["Lc"] if code_lt else None,
+                 "bit_Hc": bits["Hc"], "bit_Lc": bits["Lc"] if code_lt else None, "bit_ME": bits["mv"],
+                 "mv_hat": mv["mv_hat"], "dpb": dpb_i, "decoding_time": 0, "encoding_time": None}
+            if keep:
+                r["files"] = {k: v[1] for k, v in done.items()}
+                r["traces"] = {k: v[2] for k, v in done.items()}
+            results.append(r)
+        eng.stats["pair_s"] += time.time() - start
+        eng.stats["pairs"] += P
+        for r in results:
+            r["encoding_time"] = (time.time() - start) / P
+        return results, dpb
+
+    @torch.no_grad()
     def advance_dpb(self, ref_frame, cur_frame, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """The motion part of encode_one_stage only (pMCTF_L.py:448-495): returns the `dpb` the NEXT pair of the stage
         needs.  Used by pair-level sharding (pmctf_dist.encode_gop_pair_sharded): the context chain of the motion codec

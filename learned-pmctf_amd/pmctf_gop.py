@@ -25,6 +25,43 @@ def ca_psize(me_downsample):
     return psize * 2 if me_downsample > 4 else psize
 
 
+def encode_gop_batched(codec, frames, pic_height, pic_width, q_index, bin_folder, psize=128):
+    """The schedule of encode_gop with the pairs of each temporal stage handed to the codec in ONE call
+    (codec.encode_stage_pairs): identical files, bits and tensors, larger launches.  skip_decoding=True only."""
+    gop = len(frames)
+    stages = int(round(math.log2(gop)))
+    assert 2 ** stages == gop and gop >= 2
+    frames_coded = [None] * gop
+    bits = [None] * gop
+    bits_mv = [None] * gop
+    results = []
+    num_frames = gop
+    for stage_idx in range(stages):
+        num_frames //= 2
+        step = 2 ** stage_idx
+        code_lt = (stage_idx + 1) == stages
+        me_num = min(codec.num_me_stages - 1, stage_idx)
+        idx = [(g * 2 * step, g * 2 * step + step) for g in range(num_frames)]
+        if stage_idx == 0:
+            pairs = [(frames[a], frames[b]) for a, b in idx]
+        else:
+            pairs = [(frames_coded[a][:2], frames_coded[b][:2]) for a, b in idx]
+        paths = [os.path.join(bin_folder, f"{b}.bin") for _, b in idx]
+        rs, _ = codec.encode_stage_pairs(pairs, code_lt, {"mv_feature": None, "ref_mv_y": None}, paths,
+                                         pic_width=pic_width, pic_height=pic_height, psize=psize, stage_idx=me_num,
+                                         q_index=q_index)
+        for (i_ref, i_cur), r in zip(idx, rs):
+            frames_coded[i_ref] = [r["L_t"], r["L_tc"], None]
+            frames_coded[i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
+            bits[i_cur] = float(r["bit_H"] + r["bit_ME"])
+            bits_mv[i_cur] = float(r["bit_ME"])
+            if code_lt:
+                bits[i_ref] = float(r["bit_L"])
+                bits_mv[i_ref] = 0.0
+            results.append(r)
+    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
+
+
 def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_decoding=True, psize=128,
                on_pair=None, me_downsample=1):
     """frames: list (len = GOP size, power of two) of [Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] padded tensors.

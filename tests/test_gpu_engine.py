@@ -543,3 +543,30 @@ def test_gop_with_reduced_resolution_motion(setup):
             assert r["files"][k] == o["files"][k], k
     for (ry, rc, _), (oy, oc, _) in zip(rec, orec):
         assert_same(ry, oy, "reconstructed luma"); assert_same(rc, oc, "reconstructed chroma")
+
+
+def test_batched_stage_equals_pair_by_pair(cuda):
+    """encode_stage_pairs (all pairs of a temporal stage as one batch) against the pair-by-pair harness schedule:
+    GOP 8, four ME stages, 128x128 — every file, bit count and tensor identical."""
+    import pmctf_gop
+    net, _ = product_model(4)
+    net.engine().keep_streams = True
+    fr = frames(W, H, 8, device="cuda", seed=13)
+    with tempfile.TemporaryDirectory() as td:
+        ref = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+        ref_files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+    with tempfile.TemporaryDirectory() as td:
+        bat = pmctf_gop.encode_gop_batched(net, fr, H, W, 3, td)
+        bat_files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+    assert bat["bits"] == ref["bits"] and bat["bits_mv"] == ref["bits_mv"]
+    assert bat_files.keys() == ref_files.keys() and len(ref_files) == 3 * 7 + 2
+    for n in ref_files:
+        assert bat_files[n] == ref_files[n], n
+    for a, b in zip(bat["frames_coded"], ref["frames_coded"]):
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+    for rb, rr in zip(bat["results"], ref["results"]):
+        for k in rr["files"]:
+            assert rb["files"][k] == rr["files"][k], k
+            assert np.array_equal(rb["traces"][k][0], rr["traces"][k][0]) and \
+                np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
