@@ -570,3 +570,29 @@ def test_batched_stage_equals_pair_by_pair(cuda):
             assert rb["files"][k] == rr["files"][k], k
             assert np.array_equal(rb["traces"][k][0], rr["traces"][k][0]) and \
                 np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
+
+
+def test_headline_config_stage_batched_vs_reference(cuda):
+    """The schedule bench.py measures by default (pairs of a temporal stage as one batch) on the headline configuration,
+    against the real reference's digests: bits of every frame identical, PSNR within 1e-4 dB, and the very same files
+    as the pair-by-pair schedule."""
+    import hashlib
+    import pmctf_gop
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "reference_1920x1080_gop16_me4_digest.npz"))
+    net, _ = product_model(4)
+    net.engine().keep_streams = True
+    w, h = 1920, 1080
+    fr = frames(w, h, 16, device="cuda")
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_gop.encode_gop_batched(net, fr, h, w, 3, td)
+        batched = {n: hashlib.sha1(open(os.path.join(td, n), "rb").read()).hexdigest() for n in sorted(os.listdir(td))}
+        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+        ps = pmctf_gop.gop_psnr(rec, fr, h, w)
+    assert enc["bits"] == g["gop.bits"].tolist() and enc["bits_mv"] == g["gop.bits_mv"].tolist()
+    assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
+    del enc, rec
+    with tempfile.TemporaryDirectory() as td:
+        pmctf_gop.encode_gop(net, fr, h, w, 3, td)
+        paired = {n: hashlib.sha1(open(os.path.join(td, n), "rb").read()).hexdigest() for n in sorted(os.listdir(td))}
+    assert batched == paired and len(batched) == 47
