@@ -189,6 +189,7 @@ class HipEngine:
         # the small-plane kernels of one fill the tails of the other (per-stream LSTM state keeps them apart)
         self.side_streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
         self.multi_stream = os.environ.get("PMCTF_MULTI_STREAM", "0") == "1"   # luma/chroma on two streams
+        self.multi_stream_max_pairs = int(os.environ.get("PMCTF_MULTI_STREAM_MAX_PAIRS", "2"))
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
 

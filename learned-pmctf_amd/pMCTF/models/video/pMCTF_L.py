@@ -213,12 +213,37 @@ class pMCTF(nn.Module):
             return submit
 
         mv_hats = [m["mv_hat"] for m, _ in mvs]
-        luma = eng.compress_stage_batched([c(r[0]) for r, _ in pairs], [c(cu[0]) for _, cu in pairs], code_lt, mv_hats,
-                                          False, stage_idx, q_index, on_stream=submitter(False))
-        chroma = eng.compress_stage_batched([c(r[1]) for r, _ in pairs], [c(cu[1]) for _, cu in pairs], code_lt, mv_hats,
-                                            True, stage_idx, q_index, on_stream=submitter(True))
-        luma["finish"]()
-        chroma["finish"]()
+        def code(chroma_flag):
+            k = 1 if chroma_flag else 0
+            r = eng.compress_stage_batched([c(rf[k]) for rf, _ in pairs], [c(cu[k]) for _, cu in pairs], code_lt,
+                                           mv_hats, chroma_flag, stage_idx, q_index, on_stream=submitter(chroma_flag))
+            return r
+
+        if eng.multi_stream and P <= eng.multi_stream_max_pairs:
+            # the late stages have few pairs: luma and chroma (independent once the motion is known) share the GPU on
+            # two streams so that the small launches of one fill the gaps of the other
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            outs = []
+            for side, flag in zip(eng.side_streams, (False, True)):
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    r = code(flag)
+                    r["finish"]()
+                    outs.append(r)
+            for side in eng.side_streams[:2]:
+                main.wait_stream(side)
+            luma, chroma = outs
+            for r in outs:
+                for k in ("L_t", "H_t", "H_t_hat", "L_t_hat"):
+                    if r[k] is not None:
+                        r[k].record_stream(main)
+        else:
+            luma = code(False)
+            chroma = code(True)
+            luma["finish"]()
+            chroma["finish"]()
         results = []
         for i in range(P):
             done = {k: j.result() for k, j in jobs[i].items()}
