@@ -123,23 +123,31 @@ class Bitparm(nn.Module):
 
 
 class AEHelper:
+    """What every table owner carries: the shared range coder and its (cdf rows, row lengths, symbol offsets) as host
+    int32 arrays, None until update() has run."""
+
     def __init__(self):
         super().__init__()
         self.entropy_coder = None
-        self._offset = None
-        self._quantized_cdf = None
-        self._cdf_length = None
+        self._quantized_cdf = self._cdf_length = self._offset = None
 
     def set_entropy_coder(self, coder):
         self.entropy_coder = coder
 
     def set_cdf_info(self, quantized_cdf, cdf_length, offset):
-        self._quantized_cdf = quantized_cdf.cpu().numpy()
-        self._cdf_length = cdf_length.reshape(-1).int().cpu().numpy()
-        self._offset = offset.reshape(-1).int().cpu().numpy()
+        host = lambda t: t.detach().cpu().numpy()
+        self._quantized_cdf = host(quantized_cdf)
+        self._cdf_length = host(cdf_length.reshape(-1).int())
+        self._offset = host(offset.reshape(-1).int())
 
     def get_cdf_info(self):
         return self._quantized_cdf, self._cdf_length, self._offset
+
+    def _code(self, values, rows):
+        return self.entropy_coder.encode_with_indexes(values.reshape(-1), rows.reshape(-1), *self.get_cdf_info())
+
+    def _decode(self, rows):
+        return self.entropy_coder.decode_stream(rows.reshape(-1), *self.get_cdf_info()).reshape(rows.shape)
 
 
 class BitEstimator(AEHelper, nn.Module):
@@ -147,20 +155,19 @@ class BitEstimator(AEHelper, nn.Module):
 
     def __init__(self, channel):
         super().__init__()
-        self.f1 = Bitparm(channel)
-        self.f2 = Bitparm(channel)
-        self.f3 = Bitparm(channel)
-        self.f4 = Bitparm(channel, True)
         self.channel = channel
-
-    def forward(self, x):
-        return self.get_cdf(x)
+        for k in (1, 2, 3, 4):                      # parameter names f1..f4 are part of the checkpoint layout
+            setattr(self, f"f{k}", Bitparm(channel, final=(k == 4)))
 
     def get_logits_cdf(self, x):
-        return self.f4(self.f3(self.f2(self.f1(x))))
+        for k in (1, 2, 3, 4):
+            x = getattr(self, f"f{k}")(x)
+        return x
 
     def get_cdf(self, x):
         return torch.sigmoid(self.get_logits_cdf(x))
+
+    forward = get_cdf
 
     def _host_cdf(self):
         ps = [(f.h.detach().cpu().float(), f.b.detach().cpu().float(), None if f.a is None else f.a.detach().cpu().float())
@@ -175,48 +182,46 @@ class BitEstimator(AEHelper, nn.Module):
         return cdf
 
     def update(self, force=False, entropy_coder=None):
+        """Tables of the factorized prior, built once on the host.  Support of channel c = [-lo_c, hi_c] where lo_c / hi_c
+        is the first integer of 2..50 at which the CDF has fallen below 1e-4 / risen above 0.9999 (50 if none); the pmf of
+        an integer is cdf(v + 0.5) - cdf(v - 0.5) and what lies outside the support is the escape symbol's mass."""
         if entropy_coder is not None:
             self.entropy_coder = entropy_coder
-        if not force and self._offset is not None:
+        if self._offset is not None and not force:
             return
         with torch.no_grad():
             cdf = self._host_cdf()
-            medians = torch.zeros(self.channel)
-            minima = medians + 50
-            for i in range(50, 1, -1):
-                probs = torch.squeeze(cdf((torch.zeros_like(medians) - i)[None, :, None, None]))
-                minima = torch.where(probs < torch.zeros_like(medians) + 0.0001, torch.zeros_like(medians) + i, minima)
-            maxima = medians + 50
-            for i in range(50, 1, -1):
-                probs = torch.squeeze(cdf((torch.zeros_like(medians) + i)[None, :, None, None]))
-                maxima = torch.where(probs > torch.zeros_like(medians) + 0.9999, torch.zeros_like(medians) + i, maxima)
-            minima, maxima = minima.int(), maxima.int()
-            offset = -minima
-            pmf_start = medians - minima
-            pmf_length = maxima + minima + 1
-            max_length = pmf_length.max()
-            samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
-            lower = cdf(samples - 0.5).squeeze(0)
-            upper = cdf(samples + 0.5).squeeze(0)
-            pmf = (upper - lower)[:, 0, :]
-            tail_mass = lower[:, 0, :1] + (1.0 - upper[:, 0, -1:])
-            quantized_cdf = EntropyCoder.pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
-            self.set_cdf_info(quantized_cdf, pmf_length + 2, offset)
+            C_ = self.channel
+            grid = torch.arange(2, 51, dtype=torch.float32)                      # candidate half-widths
+            at = lambda v: cdf(v.t().reshape(-1, C_, 1, 1)).reshape(-1, C_)       # rows: candidates, cols: channels
+            left = at(-grid[None, :].expand(C_, -1))
+            right = at(grid[None, :].expand(C_, -1))
+            first = lambda hit: torch.where(hit.any(0), grid[hit.float().argmax(0)], torch.full((C_,), 50.0))
+            lo = first(left < 0.0001).int()
+            hi = first(right > 0.9999).int()
+            width = hi + lo + 1
+            longest = int(width.max())
+            pos = torch.arange(longest, dtype=torch.float32)[None, :] - lo[:, None]         # (C, longest) integer values
+            vals = pos.t().reshape(longest, C_, 1, 1)
+            below = cdf(vals - 0.5).reshape(longest, C_).t()
+            above = cdf(vals + 0.5).reshape(longest, C_).t()
+            pmf = above - below
+            outside = below[:, :1] + (1.0 - above[:, -1:])
+            table = EntropyCoder.pmf_to_cdf(pmf, outside, width, longest)
+            self.set_cdf_info(table, width + 2, -lo)
 
     @staticmethod
     def build_indexes(size):
-        N, Cc, H, W = size
-        return torch.arange(Cc, dtype=torch.int).view(1, -1, 1, 1).repeat(N, 1, H, W)
+        """table row of an element = its channel"""
+        n, c, h, w = size
+        return torch.arange(c, dtype=torch.int)[None, :, None, None].expand(n, c, h, w).contiguous()
 
     def encode(self, x):
-        indexes = self.build_indexes(x.size())
-        return self.entropy_coder.encode_with_indexes(x.reshape(-1), indexes.reshape(-1), *self.get_cdf_info())
+        return self._code(x, self.build_indexes(x.size()))
 
     def decode_stream(self, size, dtype, device):
-        output_size = (1, self.channel, size[0], size[1])
-        indexes = self.build_indexes(output_size)
-        val = self.entropy_coder.decode_stream(indexes.reshape(-1), *self.get_cdf_info())
-        return val.reshape(indexes.shape).to(dtype).to(device)
+        rows = self.build_indexes((1, self.channel, size[0], size[1]))
+        return self._decode(rows).to(dtype).to(device)
 
 
 class GaussianEncoder(AEHelper):
@@ -242,27 +247,24 @@ class GaussianEncoder(AEHelper):
         return torch.distributions.normal.Normal(torch.zeros_like(scales), scales).cdf(x)
 
     def update(self, force=False, entropy_coder=None):
+        """One table row per scale: symmetric support [-r, r] with r the first integer of 2..50 whose CDF exceeds 0.9999
+        (50 if none); pmf(v) = cdf(v + 0.5) - cdf(v - 0.5); escape mass = both tails = 2 * cdf(-r - 0.5)."""
         if entropy_coder is not None:
             self.entropy_coder = entropy_coder
-        if not force and self._offset is not None:
+        if self._offset is not None and not force:
             return
-        pmf_center = torch.zeros_like(self.scale_table) + 50
-        scales = torch.zeros_like(pmf_center) + self.scale_table
-        for i in range(50, 1, -1):
-            probs = torch.squeeze(self._cdf(torch.zeros_like(pmf_center) + i, scales))
-            pmf_center = torch.where(probs > torch.zeros_like(pmf_center) + 0.9999, torch.zeros_like(pmf_center) + i,
-                                     pmf_center)
-        pmf_center = pmf_center.int()
-        pmf_length = 2 * pmf_center + 1
-        max_length = torch.max(pmf_length).item()
-        samples = (torch.arange(max_length) - pmf_center[:, None]).float()
-        scales = torch.zeros_like(samples) + self.scale_table[:, None]
-        upper = self._cdf(samples + 0.5, scales)
-        lower = self._cdf(samples - 0.5, scales)
-        pmf = upper - lower
-        tail_mass = 2 * lower[:, :1]
-        quantized_cdf = EntropyCoder.pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
-        self.set_cdf_info(quantized_cdf, pmf_length + 2, -pmf_center)
+        S = self.scale_table
+        grid = torch.arange(2, 51, dtype=torch.float32)
+        reach = self._cdf(grid[:, None].expand(-1, S.numel()), S[None, :].expand(grid.numel(), -1)) > 0.9999
+        radius = torch.where(reach.any(0), grid[reach.float().argmax(0)], torch.full_like(S, 50.0)).int()
+        width = 2 * radius + 1
+        longest = int(width.max())
+        vals = (torch.arange(longest) - radius[:, None]).float()                  # (rows, longest)
+        sc = S[:, None].expand(-1, longest)
+        above = self._cdf(vals + 0.5, sc + torch.zeros_like(vals))
+        below = self._cdf(vals - 0.5, sc + torch.zeros_like(vals))
+        table = EntropyCoder.pmf_to_cdf(above - below, 2 * below[:, :1], width, longest)
+        self.set_cdf_info(table, width + 2, -radius)
 
     def build_indexes(self, scales):
         """Host (torch) form, kept for API parity; the encode path computes indexes on the GPU
@@ -272,10 +274,7 @@ class GaussianEncoder(AEHelper):
         return indexes.clamp_(0, self.scale_level - 1).int()
 
     def encode(self, x, scales):
-        indexes = self.build_indexes(scales)
-        return self.entropy_coder.encode_with_indexes(x.reshape(-1), indexes.reshape(-1), *self.get_cdf_info())
+        return self._code(x, self.build_indexes(scales))
 
     def decode_stream(self, scales, dtype, device):
-        indexes = self.build_indexes(scales)
-        val = self.entropy_coder.decode_stream(indexes.reshape(-1), *self.get_cdf_info())
-        return val.reshape(scales.shape).to(device).to(dtype)
+        return self._decode(self.build_indexes(scales)).to(device).to(dtype)
