@@ -187,8 +187,8 @@ def main():
     flops_all = [f for _, _, f in probe["events"]]
     # launches of this convolution differ in batch size under --schedule stages: rate = total FLOP / total time
     flops = sum(flops_all) / len(flops_all) if durs else 0.0
-    avg = sum(durs) / len(durs) if durs else float("nan")
-    achieved = sum(flops_all) / sum(durs) / 1e12 if durs else float("nan")
+    avg = sum(durs) / len(durs) if durs else None
+    achieved = sum(flops_all) / sum(durs) / 1e12 if durs else None      # None: no launch of that shape (small frames)
     peak = 157.3
     traffic = None      # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
     try:
@@ -198,15 +198,17 @@ def main():
         pass
     roofline = {"bound": "mfma", "kernel": "conv_mfma_wave_kernel<7,7> (3x3 112->112 on 576x960 subband planes, batch = pairs "
                                            "of the stage, f32 MFMA 16x16x4)",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "launches": len(durs), "avg_launch_ms": avg * 1e3, "flops_per_launch": flops, "traffic": traffic}
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": None if achieved is None else achieved / peak, "launches": len(durs),
+                "avg_launch_ms": None if avg is None else avg * 1e3, "flops_per_launch": flops, "traffic": traffic}
 
     if rank == 0:
         enc = last["enc"]
         rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
         ps = pmctf_gop.gop_psnr(rec, frames, H, W)
         out = {
-            "metric": "encoded 1080p frames/sec (GOP=16, q_index=3)", "value": value, "unit": "frames/s",
+            "metric": "encoded 1080p frames/sec (GOP=16, q_index=3)" if (W, H, args.gop, args.q_index) == (1920, 1080, 16, 3)
+            else f"encoded {W}x{H} frames/sec (GOP={args.gop}, q_index={args.q_index})", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.shard == "gops" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -596,3 +596,25 @@ def test_headline_config_stage_batched_vs_reference(cuda):
         pmctf_gop.encode_gop(net, fr, h, w, 3, td)
         paired = {n: hashlib.sha1(open(os.path.join(td, n), "rb").read()).hexdigest() for n in sorted(os.listdir(td))}
     assert batched == paired and len(batched) == 47
+
+
+def test_bench_contract_small_run(cuda):
+    """bench.py prints ONE JSON line with the driver's fields (exercised on a tiny GOP so that it takes seconds)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--width", "256", "--height", "128", "--gop", "4",
+                          "--steps", "1", "--warmup", "1", "--no_cpu_baseline"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["unit"] == "frames/s" and j["n_gpus"] == 1 and j["steps"] == 1 and j["higher_is_better"] is True
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and j["value"] > 0
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in j["roofline"], k
