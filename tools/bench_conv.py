@@ -18,6 +18,12 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("ctx112 L1 chroma 2x144x240", 2, 144, 240, 112, 112, 3, 1, 1),
     ("ctx112 L2 chroma 2x72x120", 2, 72, 120, 112, 112, 3, 1, 1),
     ("ctx112 L3 chroma 2x36x60", 2, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 8x72x120", 8, 72, 120, 112, 112, 3, 1, 1),
+    ("batched 4x72x120", 4, 72, 120, 112, 112, 3, 1, 1),
+    ("batched 16x36x60", 16, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 8x36x60", 8, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 4x144x240", 4, 144, 240, 112, 112, 3, 1, 1),
+    ("batched 8x144x240", 8, 144, 240, 112, 112, 3, 1, 1),
     ("post64 chroma 2x576x960", 2, 576, 960, 64, 64, 3, 1, 1),
     ("lstm 32->32 2x288x480", 2, 288, 480, 32, 32, 3, 1, 1),
     ("pu 16->16 960x576", 1, 960, 576, 16, 16, 3, 1, 1),
