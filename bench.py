@@ -200,7 +200,9 @@ def main():
                                            "of the stage, f32 MFMA 16x16x4)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": None if achieved is None else achieved / peak, "launches": len(durs),
-                "avg_launch_ms": None if avg is None else avg * 1e3, "flops_per_launch": flops, "traffic": traffic}
+                "avg_launch_ms": None if avg is None else avg * 1e3, "flops_per_launch": flops, "traffic": traffic,
+                "traffic_unit": "HBM bytes per 576x960x112 plane of the convolution (PMC: FETCH_SIZE x2 + WRITE_SIZE); "
+                                "algorithmic 495.9e6 B per plane; a batched launch moves N planes"}
 
     if rank == 0:
         enc = last["enc"]

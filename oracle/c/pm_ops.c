@@ -7,7 +7,7 @@
  * kernels in learned-pmctf_amd/csrc follow the same order and are compared
  * bit-for-bit against these in tests/.
  *
- * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp -shared -fPIC
+ * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -pthread -shared -fPIC   (oracle/Makefile)
  */
 #include "pm_math.h"
 #include <immintrin.h>
