@@ -618,3 +618,23 @@ def test_bench_contract_small_run(cuda):
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and j["value"] > 0
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in j["roofline"], k
+
+
+@pytest.mark.parametrize("gop,size", [(2, (128, 128)), (32, (128, 128)), (4, (200, 120))])
+def test_batched_schedule_other_gop_sizes(cuda, gop, size):
+    """GOP 2 (one stage), GOP 32 (five stages, 16 pairs in the first batch, more stages than motion models) and a frame
+    size that needs padding: stage-batched files, bits and subband tree equal the pair-by-pair schedule."""
+    import pmctf_gop
+    net, _ = product_model(4)
+    w, h = size
+    fr = frames(w, h, gop, device="cuda", seed=gop)
+    with tempfile.TemporaryDirectory() as td:
+        a = pmctf_gop.encode_gop(net, fr, h, w, 5, td)
+        fa = {n: open(os.path.join(td, n), "rb").read() for n in os.listdir(td)}
+    with tempfile.TemporaryDirectory() as td:
+        b = pmctf_gop.encode_gop_batched(net, fr, h, w, 5, td)
+        fb = {n: open(os.path.join(td, n), "rb").read() for n in os.listdir(td)}
+    assert a["bits"] == b["bits"] and a["bits_mv"] == b["bits_mv"] and fa == fb and len(fa) == 3 * (gop - 1) + 2
+    for p, q in zip(a["frames_coded"], b["frames_coded"]):
+        for x, y in zip(p, q):
+            assert (x is None and y is None) or torch.equal(x, y)
