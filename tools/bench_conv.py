@@ -18,6 +18,7 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("ctx112 L1 chroma 2x144x240", 2, 144, 240, 112, 112, 3, 1, 1),
     ("ctx112 L2 chroma 2x72x120", 2, 72, 120, 112, 112, 3, 1, 1),
     ("ctx112 L3 chroma 2x36x60", 2, 36, 60, 112, 112, 3, 1, 1),
+    ("batched L0 luma 8x576x960", 8, 576, 960, 112, 112, 3, 1, 1),
     ("batched 8x72x120", 8, 72, 120, 112, 112, 3, 1, 1),
     ("batched 4x72x120", 4, 72, 120, 112, 112, 3, 1, 1),
     ("batched 16x36x60", 16, 36, 60, 112, 112, 3, 1, 1),
