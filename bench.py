@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — encoded 1080p frames/s of the pMCTF temporal-decomposition encode path on MI355X.
 
-One "step" = one full GOP-16 encode of 1920x1080 4:2:0 frames at q_index=3 through the drop-in API
-(pMCTF.encode_one_stage for 15 pairs + the final L frame; bitstreams written by the host range
-coder), inputs already resident in HBM.  N GPUs encode N independent GOPs (closed GOPs are
-independent units: no data-path collective; weak scaling).  Prints ONE JSON line on rank 0.
+One "step" = one full GOP-16 encode of 1920x1080 4:2:0 frames at q_index=3, inputs already resident in HBM,
+bitstreams written by the host range coder.
+
+`value` is measured through the DROP-IN path: pMCTF.encode_one_stage called pair by pair, exactly the schedule of the
+reference's harness (test_pMCTF_flex.py:214-223) — 15 pairs + the final L frame per GOP.  In the same run, after the
+timed region, rank 0 also measures (auxiliary figures, never `value`):
+  * `stage_batched`     — all pairs of a temporal stage in one call (pMCTF.encode_stage_pairs): same files and bits,
+                          larger launches;
+  * `cross_gop_batched` — the same with stage s of K closed GOPs in one call (pmctf_gop.encode_gops_batched);
+  * `cpu_baseline`      — the oracle's ATen-CPU restatement timed on one full-size 1080p pair on the host cores.
+N GPUs encode N independent GOPs (closed GOPs are independent units: no data-path collective; weak scaling).
+Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -12,6 +20,7 @@ independent units: no data-path collective; weak scaling).  Prints ONE JSON line
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -19,71 +28,118 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
 
-import torch  # noqa: E402
+# work of one 1080p pair in GMAC: coded frame 10 186, SpyNet 707, MV codec 163, temporal P+U 32.5
+_W_FRAME, _W_MOTION = 10186.0, 707.0 + 163.0 + 32.5
+PEAK_F32_MFMA = 157.3          # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
-def cpu_baseline(width, height, gop):
-    """The oracle's restatement with the ATen CPU ops the reference itself calls ("port"), timed on a bounded
-    sample: one H pair and one H+L pair at 256x448 (BASELINE config 2 size), scaled by padded pixel count
-    to the 1080p GOP (work is linear in pixels)."""
+def cpu_baseline(width, height, gop, q_index):
+    """The oracle's restatement with the ATen CPU ops the reference itself calls (kind "port"), timed on the host cores
+    on a bounded sample of the SAME workload: one full-size H pair of the 1080p sequence (stage 0, no L).  The pair that
+    also codes L does one more coded frame: t_HL = t_H * (2*10186 + 902.5) / (10186 + 902.5) by the conv work of
+    BASELINE.md §3; GOP time = (gop-2)*t_H + t_HL.  The former 448x256 sample (cache-resident, optimistic) is timed as
+    well and reported beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
     import pmctf_synth
     from pmctf_oracle.model import Oracle
     from pMCTF.models.video.pMCTF_L import pMCTF
-    w, h = 448, 256
-    # a 1-GPU box owns a 16-CPU share of the host: use that many threads (and report them as `cores`)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, avail)))
+    torch.set_num_threads(max(1, min(16, avail)))       # a 1-GPU box owns a 16-CPU share of the host
     net = pMCTF(num_me_stages=1)
     sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
     orc = Oracle(sd, 1, "torch")
-    fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(w, h, 2)]
     dpb = {"mv_feature": None, "ref_mv_y": None}
-    with torch.no_grad():
-        t0 = time.time()
-        r = orc.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=w, pic_height=h, q_index=3)
-        t_h = time.time() - t0
-        t0 = time.time()
-        orc.encode_one_stage(fr[0], fr[1], True, r["dpb"], pic_width=w, pic_height=h, q_index=3)
-        t_hl = time.time() - t0
-    ph, pw = -(-h // 128) * 128, -(-w // 128) * 128
+
+    def time_pair(w, h, code_lt):
+        fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(w, h, 2)]
+        with torch.no_grad():
+            t0 = time.time()
+            orc.encode_one_stage(fr[0], fr[1], code_lt, dpb, pic_width=w, pic_height=h, q_index=q_index)
+            return time.time() - t0
+
+    ratio = (2 * _W_FRAME + _W_MOTION) / (_W_FRAME + _W_MOTION)
+    t_small = time_pair(448, 256, False)
+    t_small_hl = time_pair(448, 256, True)
+    t_h = time_pair(width, height, False)
+    t_gop = (gop - 2) * t_h + ratio * t_h
+    ph, pw = 256, 512
     PH, PW = -(-height // 128) * 128, -(-width // 128) * 128
     scale = (PH * PW) / (ph * pw)
-    t_gop = ((gop - 2) * t_h + t_hl) * scale
     return {"value": gop / t_gop, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (ATen CPU ops, as the reference's CPU path) on one H pair ({t_h:.1f} s) and one H+L "
-                      f"pair ({t_hl:.1f} s) at {w}x{h}, scaled x{scale:.1f} by padded pixels to {gop - 2}*t_H + t_HL"}
+            "sample": f"oracle (ATen CPU ops, as the reference's CPU path) on ONE full-size {width}x{height} H pair: "
+                      f"t_H = {t_h:.1f} s; GOP = {gop - 2}*t_H + t_HL with t_HL = {ratio:.3f}*t_H (conv work ratio)",
+            "t_h_pair_s": t_h,
+            "small_sample_value": gop / (((gop - 2) * t_small + t_small_hl) * scale),
+            "small_sample": f"one H pair ({t_small:.1f} s) and one H+L pair ({t_small_hl:.1f} s) at 448x256 scaled "
+                            f"x{scale:.1f} by padded pixels (cache-resident: optimistic)"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process
+    (nothing has touched the GPU in this process yet) and exit with its status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def roofline_of(events, kernel, traffic):
+    """dominant-kernel roofline from HIP events recorded on the launch stream inside the timed region"""
+    durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in events]
+    flops_all = [f for _, _, f in events]
+    # launches of this convolution can differ in batch size: rate = total FLOP / total time
+    achieved = sum(flops_all) / sum(durs) / 1e12 if durs else None     # None: no launch of that shape (small frames)
+    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+            "frac": None if achieved is None else achieved / PEAK_F32_MFMA, "launches": len(durs),
+            "avg_launch_ms": sum(durs) / len(durs) * 1e3 if durs else None,
+            "flops_per_launch": sum(flops_all) / len(flops_all) if durs else 0.0, "traffic": traffic,
+            "traffic_unit": "HBM bytes per 576x960x112 plane of the convolution (rocprofv3 --pmc passes committed under "
+                            "profiles/: FETCH_SIZE x2 + WRITE_SIZE); algorithmic 495.9e6 B per plane; a launch over N "
+                            "planes moves N times that"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--q_index", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--schedule", choices=("pairs", "stages"), default="stages",
-                    help="pairs: the harness schedule, one encode_one_stage call per frame pair.  stages: the pairs of "
-                         "each temporal stage as one batch (encode_stage_pairs): same files and bits, larger launches.")
+    ap.add_argument("--no_aux", action="store_true", help="skip the auxiliary schedules measured after the timed region")
+    ap.add_argument("--schedule", choices=("pairs", "stages"), default="pairs",
+                    help="what `value` times.  pairs (default): the reference harness's schedule, one encode_one_stage "
+                         "call per frame pair.  stages: the pairs of each temporal stage as one batch "
+                         "(encode_stage_pairs): same files and bits, larger launches.")
+    ap.add_argument("--cross_gops", type=int, default=4, help="K of the auxiliary cross-GOP stage-batched figure")
     ap.add_argument("--inflight", type=int, default=1,
                     help="closed GOPs coded concurrently on this GPU (one host thread + HIP stream each; a step is then "
                          "`inflight` GOPs).  1 keeps the per-kernel event timing of the roofline probe undisturbed.")
     ap.add_argument("--shard", choices=("gops", "pairs"), default="gops",
                     help="gops: every rank codes its own GOP (weak scaling, no data-path collective; the default the "
-                         "driver measures).  pairs: ONE GOP, the pairs of each temporal stage spread over the ranks "
-                         "with an all-gather of the subband tree per stage (strong scaling, <= 4x by the 4-stage "
-                         "critical path).")
+                         "driver measures).  pairs: ONE GOP, the pairs of each temporal stage spread over the ranks, "
+                         "motion context relayed rank to rank, one all-gather of the subband tree per stage (strong "
+                         "scaling, <= 4x by the 4-stage critical path).")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -112,9 +168,12 @@ def main():
     net.update(force=True)
 
     W, H = args.width, args.height
+
+    def gop_frames(seed):
+        return [list(pmctf_synth.frames_to_tensors(f, device=dev)) for f in pmctf_synth.synth_yuv420(W, H, args.gop, seed=seed)]
+
     # every rank codes its own GOP (different frames of the synthetic sequence)
-    f8 = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234 + (rank if args.shard == "gops" else 0))
-    frames = [list(pmctf_synth.frames_to_tensors(f, device=dev)) for f in f8]
+    frames = gop_frames(1234 + (rank if args.shard == "gops" else 0))
     PH, PW = frames[0][0].shape[2], frames[0][0].shape[3]
     sub_h, sub_w = PH // 2, PW // 2
 
@@ -126,8 +185,7 @@ def main():
     last = {}
     extra = []      # --inflight > 1: further GOPs of the synthetic sequence, each with its own stream and output folder
     for k in range(1, args.inflight):
-        fk = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234 + rank + 1000 * k)
-        extra.append(([list(pmctf_synth.frames_to_tensors(f, device=dev)) for f in fk], torch.cuda.Stream(device=dev),
+        extra.append((gop_frames(1234 + rank + 1000 * k), torch.cuda.Stream(device=dev),
                       tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_g{k}_")))
 
     def code_extra(fr, stream, folder):
@@ -136,15 +194,6 @@ def main():
             (pmctf_gop.encode_gop_batched if args.schedule == "stages" else pmctf_gop.encode_gop)(
                 net, fr, H, W, args.q_index, folder)
         stream.synchronize()
-
-    def step():
-        import threading
-        workers = [threading.Thread(target=code_extra, args=e) for e in extra]
-        for t in workers:
-            t.start()
-        step_main()
-        for t in workers:
-            t.join()
 
     def step_main():
         if args.shard == "pairs" and world > 1:
@@ -156,25 +205,38 @@ def main():
             enc = pmctf_gop.encode_gop(net, frames, H, W, args.q_index, tmp)
         last["enc"] = enc
 
+    def step():
+        import threading
+        workers = [threading.Thread(target=code_extra, args=e) for e in extra]
+        for t in workers:
+            t.start()
+        step_main()
+        for t in workers:
+            t.join()
+
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+    def timed(fn, steps, warmup):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; the dominant convolution's launches
+        inside the timed region are bracketed by HIP events on the launch stream"""
+        for _ in range(warmup):
+            fn()
         sync()
         probe = {"match": dominant, "events": []}
         ops.CONV_PROBE = probe
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        for _ in range(steps):
+            fn()
+        sync()
         elapsed = time.perf_counter() - t0
         ops.CONV_PROBE = None
+        return elapsed, probe["events"]
+
+    with torch.no_grad():
+        elapsed, events = timed(step, args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,55 +244,50 @@ def main():
 
     frames_total = args.gop * args.steps * (world if args.shard == "gops" else 1) * args.inflight
     value = frames_total / elapsed
-    # dominant-kernel roofline from the live HIP events
-    durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in probe["events"]]
-    flops_all = [f for _, _, f in probe["events"]]
-    # launches of this convolution differ in batch size under --schedule stages: rate = total FLOP / total time
-    flops = sum(flops_all) / len(flops_all) if durs else 0.0
-    avg = sum(durs) / len(durs) if durs else None
-    achieved = sum(flops_all) / sum(durs) / 1e12 if durs else None      # None: no launch of that shape (small frames)
-    peak = 157.3
-    traffic = None      # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (profiles/)
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_dominant_kernel.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_wave_kernel<7,7> (3x3 112->112 on 576x960 subband planes, batch = pairs "
-                                           "of the stage, f32 MFMA 16x16x4)",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": None if achieved is None else achieved / peak, "launches": len(durs),
-                "avg_launch_ms": None if avg is None else avg * 1e3, "flops_per_launch": flops, "traffic": traffic,
-                "traffic_unit": "HBM bytes per 576x960x112 plane of the convolution (PMC: FETCH_SIZE x2 + WRITE_SIZE); "
-                                "algorithmic 495.9e6 B per plane; a batched launch moves N planes"}
+    traffic = None      # HBM bytes per plane of this kernel from the committed rocprofv3 --pmc passes (profiles/)
+    for name in ("round2_dominant_kernel.json", "round1_dominant_kernel.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+            break
+        except (OSError, KeyError, ValueError):
+            pass
+    kname = {"pairs": "3x3 112->112 conv on one 576x960 luma subband plane per launch: conv_mfma_wave_kernel<7,7> for the "
+                      "rows that fill whole rounds of workgroups + conv_mfma_pipe_kernel<7,1,1,6> for the remainder",
+             "stages": "conv_mfma_wave_kernel<7,7> (3x3 112->112 on 576x960 subband planes, batch = pairs of the stage)"}
+    roofline = roofline_of(events, kname[args.schedule] + ", f32 MFMA 16x16x4", traffic)
+    sched_text = {"pairs": "encode_one_stage pair by pair (the reference harness's schedule, test_pMCTF_flex.py:214-223)",
+                  "stages": "all pairs of a temporal stage as one batch (encode_stage_pairs)"}
 
     if rank == 0:
         enc = last["enc"]
         rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
         ps = pmctf_gop.gop_psnr(rec, frames, H, W)
+        headline = (W, H, args.gop, args.q_index) == (1920, 1080, 16, 3)
         out = {
-            "metric": "encoded 1080p frames/sec (GOP=16, q_index=3)" if (W, H, args.gop, args.q_index) == (1920, 1080, 16, 3)
+            "metric": "encoded 1080p frames/sec (GOP=16, q_index=3)" if headline
             else f"encoded {W}x{H} frames/sec (GOP={args.gop}, q_index={args.q_index})", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.shard == "gops" else "strong",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.shard == "gops" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 GOP-{args.gop} q_index={args.q_index} full pMCTF encode "
                                    f"(write_stream, skip_decoding), num_me_stages={net.num_me_stages}",
-                       "schedule": "all pairs of a temporal stage as one batch (encode_stage_pairs)"
-                       if args.schedule == "stages" else "pair by pair (encode_one_stage, the harness schedule)",
+                       "schedule": sched_text[args.schedule],
                        "frames_per_step": args.gop * args.inflight, "gops_in_flight_per_gpu": args.inflight,
                        "parallelism": f"gop-dp{world}" if args.shard == "gops" else f"pair-shard{world}",
                        "weights": "deterministic synthetic (pmctf_synth seed 0)"},
             "roofline": roofline,
             "bpp": sum(enc["bits"]) / (args.gop * W * H),
             "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
-            "host": dict(net.engine().stats),
         }
         # "+ bpp/PSNR parity vs CPU ref" of BASELINE's metric: rank 0 codes exactly the sequence the real reference was
-        # run on (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4); compare with
-        # the digests of that run (data, tests/golden/).
-        fix = os.path.join(ROOT, "tests", "golden", f"reference_{W}x{H}_gop{args.gop}_me{net.num_me_stages}_digest.npz")
-        if args.q_index == 3 and os.path.exists(fix):
+        # run on (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4 [--q_index q]);
+        # compare with the digests of that run (data, tests/golden/).
+        qs = "" if args.q_index == 3 else f"_q{args.q_index}"
+        fix = os.path.join(ROOT, "tests", "golden",
+                           f"reference_{W}x{H}_gop{args.gop}_me{net.num_me_stages}{qs}_digest.npz")
+        if os.path.exists(fix):
             import numpy as np
             g = np.load(fix)
             out["parity_vs_reference_cpu"] = {
@@ -239,24 +296,39 @@ def main():
                 "psnr_yuv_reference": float(g["gop.psnr_yuv"].mean()),
                 "psnr_max_abs_err_db": float(max(abs(p["yuv"] - r) for p, r in zip(ps, g["gop.psnr_yuv"].tolist()))),
             }
-        if world == 1 and args.inflight == 1 and not args.no_cpu_baseline:
-            # Auxiliary figure (not `value`): the same GPU with TWO closed GOPs in flight (second host thread + HIP
-            # stream).  Concurrency fills the latency-bound small-plane kernels; per-kernel event timing is meaningless
-            # in that mode, which is why the headline run keeps one GOP in flight.
-            fk = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234 + 1000)
-            extra.append(([list(pmctf_synth.frames_to_tensors(f, device=dev)) for f in fk], torch.cuda.Stream(device=dev),
-                          tempfile.mkdtemp(prefix="pmctf_bench_g1_")))
+        del rec
+        if world == 1 and args.inflight == 1 and not args.no_aux:
+            aux_steps = max(1, min(args.steps, 5))
             with torch.no_grad():
-                step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter() - t1
-            out["two_gops_in_flight"] = {"value": 2 * args.gop / t1, "unit": "frames/s", "ms_per_step": t1 * 1e3,
-                                         "frames_per_step": 2 * args.gop}
+                if args.schedule == "pairs":
+                    def batched():
+                        last["enc"] = pmctf_gop.encode_gop_batched(net, frames, H, W, args.q_index, tmp)
+                    t_b, ev_b = timed(batched, aux_steps, 1)
+                    out["stage_batched"] = {
+                        "value": args.gop * aux_steps / t_b, "unit": "frames/s", "ms_per_step": t_b / aux_steps * 1e3,
+                        "steps": aux_steps, "schedule": sched_text["stages"],
+                        "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"],
+                        "roofline": roofline_of(ev_b, kname["stages"] + ", f32 MFMA 16x16x4", traffic)}
+                K = args.cross_gops
+                if K > 1 and hasattr(pmctf_gop, "encode_gops_batched"):
+                    gops = [frames] + [gop_frames(1234 + 1000 * k) for k in range(1, K)]
+                    folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_x{k}_") for k in range(1, K)]
+
+                    def cross():
+                        last["encs"] = pmctf_gop.encode_gops_batched(net, gops, H, W, args.q_index, folders)
+                    k_steps = max(1, min(args.steps, 2))
+                    t_x, ev_x = timed(cross, k_steps, 1)
+                    out["cross_gop_batched"] = {
+                        "value": K * args.gop * k_steps / t_x, "unit": "frames/s", "ms_per_step": t_x / k_steps * 1e3,
+                        "steps": k_steps, "gops_per_step": K, "frames_per_step": K * args.gop,
+                        "schedule": f"stage s of {K} closed GOPs as one batch (pmctf_gop.encode_gops_batched)",
+                        "bits_identical_to_headline": last["encs"][0]["bits"] == enc["bits"],
+                        "roofline": roofline_of(ev_x, kname["stages"] + ", f32 MFMA 16x16x4", traffic)}
+                    del gops
+                    last.pop("encs", None)
+        out["host"] = dict(net.engine().stats)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, args.gop)
+            out["cpu_baseline"] = cpu_baseline(W, H, args.gop, args.q_index)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

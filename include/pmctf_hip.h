@@ -153,6 +153,20 @@ int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *a, const in
  * (3 identical channels, pMCTF_L.py:453-454): planes im1[HW], warped[HW], flow_up[2][HW] -> NHWC [HW,8]. */
 int pmctf_spynet_pack8_f32(const float *im1, const float *warped, const float *flow_up, float *out, int H, int W,
                            void *stream);
+/* The whole PredictUpdate CNN of a lifting step as ONE launch (pu_fused.hip): 1->16, 16->16 tanh, 16->16 (+c1), 16->1,
+ * 3x3 zero-padded, with the arithmetic around it.  x / other / out: single-channel planes (N,1,H,W).
+ *   mode 0 — temporal predict / update filter, pMCTF/layers/wavelet_transform_temporal_mctf.py:27-45:
+ *            out = (x + PU(x) * 0.1) * c                                     (c = 1/sqrt2 predict, 0.5 update)
+ *   mode 1 — one branch of the iWave lifting step, pMCTF/layers/lifting_1d.py:103-145 (forward) / :147-189 (backward):
+ *            skip = conv3x1(reflect_pad_H(x)) + lbias;  out = other + sign * (skip + (PU(skip / 256) * 256) * 0.1)
+ * PredictUpdate itself: pMCTF/layers/lifting_1d.py:25-49.  w1/b1, w4/b4: OIHW device filters (16,1,3,3)+(16), (1,16,3,3)+(1);
+ * w2/w3: pmctf_conv2d_pack_weights() output for the two (16,16,3,3) layers.  Same sums, same order as the separate
+ * launches (pmctf_conv3x3_cin1_dual_f32, pmctf_conv2d_nhwc_f32, pmctf_conv2d_fewcout_f32, pmctf_lift_skip3_f32, pmctf_ew_f32). */
+int pmctf_predict_update_fused_f32(const float *x, const float *other, float *out, const float *w1, const float *b1,
+                                   const float *w2_packed, const float *b2_packed, const float *w3_packed,
+                                   const float *b3_packed, const float *w4, const float *b4, int N, int H, int W, int mode,
+                                   float c, float sign, float lw0, float lw1, float lw2, float lbias, void *stream);
+
 /* ReflectionPad2d((0,0,1,1)) + 3x1 conv on NC single-channel planes (lifting_1d.py:98,105-106) */
 int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2, float bias,
                          void *stream);

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "pm_device_math.h"
 #include "launch.h"
 #include "../../include/pmctf_hip.h"
@@ -752,19 +753,30 @@ void choose_mt(int Cout, int &MT, int &MB) {
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
                   {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}};
+std::once_flag g_knobs_once;
 inline long knob(const char *name) {
-    for (Knob &k : g_knobs)
-        if (!strcmp(k.name, name)) {
+    // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
+    std::call_once(g_knobs_once, [] {
+        for (Knob &k : g_knobs)
             if (!k.set) {
                 char env[64];
-                snprintf(env, sizeof env, "PMCTF_CONV_%s", name);
+                snprintf(env, sizeof env, "PMCTF_CONV_%s", k.name);
                 const char *v = getenv(env);
                 if (v) k.value = atol(v);
                 k.set = true;
             }
-            return k.value;
-        }
+    });
+    for (Knob &k : g_knobs)
+        if (!strcmp(k.name, name)) return k.value;
     return 0;
+}
+
+// dynamic LDS above the 64 KB default needs the function attribute: set it once per kernel instantiation, thread-safe
+template <typename K>
+inline void allow_big_lds(K kernel, std::once_flag &once) {
+    std::call_once(once, [kernel] {
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
 }
 
 // wave-private variant usable? (stride-1-ish patch of one wave must fit 7 staging slots and 80 KB for the workgroup)
@@ -794,6 +806,8 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         if (MT >= 4 && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+            static std::once_flag once_w;
+            allow_big_lds(conv_mfma_wave_kernel<MT, 7>, once_w);
             PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
             return pm_launch_status();
         }
@@ -805,16 +819,19 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         // filters; the single-buffer variant keeps 3 waves/SIMD for MT<=4 and wins on 3x3/7x7 there.
         const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1);
         if (!v1_only && prefer_v2 && (a.Cin % CB) == 0 && 2 * smem <= 80 * 1024 && slots <= 9) {
-            if (slots <= 6) PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 6>), grid, dim3(256), 2 * smem, st, b);
-            else PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 9>), grid, dim3(256), 2 * smem, st, b);
+            static std::once_flag once_p6, once_p9;
+            if (slots <= 6) {
+                allow_big_lds(conv_mfma_pipe_kernel<MT, NT, TW16, 6>, once_p6);
+                PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 6>), grid, dim3(256), 2 * smem, st, b);
+            } else {
+                allow_big_lds(conv_mfma_pipe_kernel<MT, NT, TW16, 9>, once_p9);
+                PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 9>), grid, dim3(256), 2 * smem, st, b);
+            }
             return pm_launch_status();
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv_mfma_kernel<MT, NT, TW16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static std::once_flag once_s;
+    allow_big_lds(conv_mfma_kernel<MT, NT, TW16>, once_s);
     PM_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
     return pm_launch_status();
 }
@@ -892,13 +909,13 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
             const long total = bands * per_band, rounds = total / slots;
             const long padded = (total + 255) / 256 * 256;
             const long bands_a = rounds * slots / per_band;
-            if (rounds >= 1 && bands_a < bands && (padded - total) * 100 > 3 * total) {
+            if (rounds >= 1 && bands_a >= 1 && bands_a < bands && (padded - total) * 100 > 3 * total) {
                 const int rows_a = (int)bands_a * 8;
                 const int rc = launch<MTP, 4, 2>(a, MB, st, 0, rows_a);
                 if (rc != PMCTF_OK) return rc;
                 return launch<MTP, 1, 1>(a, MB, st, rows_a, a.Ho);
             }
-            if (rounds < 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+            if (rounds < 1 || bands_a < 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
         }
         if (px >= 400000L || (MTP >= 4 && wave_eligible(a))) return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);
     }

@@ -190,6 +190,8 @@ class HipEngine:
         self.side_streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
         self.multi_stream = os.environ.get("PMCTF_MULTI_STREAM", "0") == "1"   # luma/chroma on two streams
         self.multi_stream_max_pairs = int(os.environ.get("PMCTF_MULTI_STREAM_MAX_PAIRS", "2"))
+        self.pu_fused = os.environ.get("PMCTF_PU_FUSED", "1") != "0"     # one launch per PredictUpdate + lifting step
+        self.post_process_max_px = 8 * 1152 * 1920      # pixels per post-processing launch group (4.5 GB per 64-ch map)
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
 
@@ -235,13 +237,22 @@ class HipEngine:
         out = self.conv(p + ".conv4", 1, 1)(t)
         return out.view(N, 1, H, W)
 
+    def pu_convs(self, p):
+        return tuple(self.conv(f"{p}.conv{k}", 1, 1) for k in (1, 2, 3, 4))
+
     def predict_filter(self, stage, x):
         """wavelet_transform_temporal_mctf.py:27-35: (x + 0.1*P(x)) * (1/sqrt2)"""
-        pu = self.predict_update(f"temporal_filtering.{stage}.P_t", x)
+        p = f"temporal_filtering.{stage}.P_t"
+        if self.pu_fused:
+            return ops.predict_update_fused(x, None, self.pu_convs(p), 0, c=1 / math.sqrt(2))
+        pu = self.predict_update(p, x)
         return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 1 / math.sqrt(2))
 
     def update_filter(self, stage, x):
-        pu = self.predict_update(f"temporal_filtering.{stage}.U_t", x)
+        p = f"temporal_filtering.{stage}.U_t"
+        if self.pu_fused:
+            return ops.predict_update_fused(x, None, self.pu_convs(p), 0, c=0.5)
+        pu = self.predict_update(p, x)
         return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 0.5)
 
     # ------------------------------------------------------------------ a5/a7 (pMCTF_L.py:297-330)
@@ -414,10 +425,14 @@ class HipEngine:
 
     def compress_mv(self, ref_y, cur_y, dpb, stage_idx=0, q_index=0, estimate=False, me_downsample=1):
         """estimate=True: compute_and_code_motion (pMCTF_L.py:244-292): same networks, unrounded quantisation steps,
-        bit estimates (two device float64: y, z) instead of a symbol stream"""
+        bit estimates (two device float64: y, z) instead of a symbol stream.
+        dpb may be a zero-argument callable: it is evaluated after the motion ESTIMATION (which needs no context), so
+        a caller that receives the context from another GPU overlaps the wait with SpyNet (pmctf_dist relay)."""
         s = min(self.num_me_stages - 1, stage_idx)
         q_enc, q_dec = self.get_mv_y_q(q_index, s, inference=not estimate)
         est_mv = self.spynet(cur_y, ref_y, me_downsample=me_downsample)
+        if callable(dpb):
+            dpb = dpb()
         mv_y = self.mv_enc(s, est_mv, self.to_nhwc_input(dpb["mv_feature"]), q_enc)
         mv_z = self.mv_hyper_enc(s, mv_y)
         _, hy, wy, _ = mv_y.shape
@@ -462,24 +477,33 @@ class HipEngine:
         pu = self.predict_update(f"{wt}.{pu_name}", ew(EW_DIVS, skip, alpha=256.0))
         return ew(EW_ADD_MULS2, skip, pu, 256.0, 0.1)
 
+    def lift_step(self, wt, conv_name, pu_name, src, other, sign):
+        """other + sign * branch(src): one lifting step (lifting_1d.py:105-118 forward, :150-163 backward)"""
+        if self.pu_fused and src.shape[2] >= 2:
+            w = self.sd[f"{wt}.{conv_name}.weight"].reshape(-1).tolist()
+            b = float(self.sd[f"{wt}.{conv_name}.bias"].reshape(-1)[0])
+            return ops.predict_update_fused(src, other, self.pu_convs(f"{wt}.{pu_name}"), 1, sign=sign,
+                                            lift=(w[0], w[1], w[2], b))
+        return ew(EW_ADD if sign > 0 else EW_SUB, other, self.lift_branch(wt, conv_name, pu_name, src))
+
     def forward_lift(self, wt, x):
         """iWave1D.forward_lift along H (lifting_1d.py:103-145); x plane (N,1,H,W) -> l, h (N,1,H/2,W)"""
         x_e = ew(EW_COPY, x[:, :, ::2, :])
         x_o = ew(EW_COPY, x[:, :, 1::2, :])
-        x_o = ew(EW_ADD, x_o, self.lift_branch(wt, "conv_P1", "P_1", x_e))
-        x_e = ew(EW_ADD, x_e, self.lift_branch(wt, "conv_U1", "U_1", x_o))
-        x_o = ew(EW_ADD, x_o, self.lift_branch(wt, "conv_P2", "P_2", x_e))
-        x_e = ew(EW_ADD, x_e, self.lift_branch(wt, "conv_U2", "U_2", x_o))
+        x_o = self.lift_step(wt, "conv_P1", "P_1", x_e, x_o, 1.0)
+        x_e = self.lift_step(wt, "conv_U1", "U_1", x_o, x_e, 1.0)
+        x_o = self.lift_step(wt, "conv_P2", "P_2", x_e, x_o, 1.0)
+        x_e = self.lift_step(wt, "conv_U2", "U_2", x_o, x_e, 1.0)
         return ew(EW_MULS, x_e, alpha=SCALE_L), ew(EW_MULS, x_o, alpha=SCALE_H)
 
     def backward_lift(self, wt, l, h):
         """iWave1D.backward_lift (lifting_1d.py:147-189)"""
         l = ew(EW_DIVS, l, alpha=SCALE_L)
         h = ew(EW_DIVS, h, alpha=SCALE_H)
-        l = ew(EW_SUB, l, self.lift_branch(wt, "conv_U2", "U_2", h))
-        h = ew(EW_SUB, h, self.lift_branch(wt, "conv_P2", "P_2", l))
-        l = ew(EW_SUB, l, self.lift_branch(wt, "conv_U1", "U_1", h))
-        h = ew(EW_SUB, h, self.lift_branch(wt, "conv_P1", "P_1", l))
+        l = self.lift_step(wt, "conv_U2", "U_2", h, l, -1.0)
+        h = self.lift_step(wt, "conv_P2", "P_2", l, h, -1.0)
+        l = self.lift_step(wt, "conv_U1", "U_1", h, l, -1.0)
+        h = self.lift_step(wt, "conv_P1", "P_1", l, h, -1.0)
         N, _, H2, W = l.shape
         x = ops.empty_planar(N, 1, 2 * H2, W, self.dev)
         ew(EW_COPY, l, out=x[:, :, ::2, :])
@@ -599,6 +623,12 @@ class HipEngine:
         """returns (x/in_div + net(x/in_div)) * out_mul"""
         p = f"{coder}.dequantModule"
         N, _, H, W = x.shape
+        # large batches (stage s of several GOPs at once): 64-channel full-resolution maps are the biggest tensors of
+        # the path — bound them by working through the planes in groups (planes are independent; same arithmetic)
+        cap = self.post_process_max_px
+        if N > 1 and N * H * W > cap:
+            per = max(1, cap // (H * W))
+            return torch.cat([self.post_process(coder, x[i:i + per], in_div, out_mul) for i in range(0, N, per)], dim=0)
         xs = ew(EW_DIVS, x, alpha=in_div) if in_div != 1.0 else x
         tmp = self.conv(p + ".conv1", 1, 1)(xs.view(N, H, W, 1))
         conv1 = tmp

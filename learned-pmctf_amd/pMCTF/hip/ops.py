@@ -233,6 +233,20 @@ def lift_skip3(x, w3, bias):
     return y
 
 
+def predict_update_fused(x, other, pu, mode, c=1.0, sign=1.0, lift=(0.0, 0.0, 0.0, 0.0)):
+    """pu: (conv1, conv2, conv3, conv4) Conv2d objects of one PredictUpdate block.  mode 0: (x + PU(x)*0.1)*c;
+    mode 1: other + sign * (skip + PU(skip/256)*256*0.1) with skip = reflect 3x1 conv of x (lift = w0, w1, w2, bias)."""
+    c1, c2, c3, c4 = pu
+    N, Cc, H, W = x.shape
+    assert Cc == 1 and c1.small and c4.few and not c2.small and not c2.few
+    out = torch.empty_like(x)
+    _lib.check(_lib.hip().pmctf_predict_update_fused_f32(
+        _p(x), _p(other), _p(out), _p(c1.w), _p(c1.b), _p(c2.w), _p(c2.b), _p(c3.w), _p(c3.b), _p(c4.w), _p(c4.b),
+        N, H, W, int(mode), float(c), float(sign), float(lift[0]), float(lift[1]), float(lift[2]), float(lift[3]),
+        _stream()), "predict_update_fused")
+    return out
+
+
 def nearest_up2(x):
     N, H, W, Cc = x.shape
     y = empty_nhwc(N, 2 * H, 2 * W, Cc, x.device)

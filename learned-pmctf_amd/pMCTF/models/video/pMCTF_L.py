@@ -9,9 +9,10 @@ on host threads.  There is no CPU fallback: without a GPU and the built librarie
 
 Implemented: the write-stream encode branch (pMCTF_L.py:553-637) with skip_decoding True or False (real decoder:
 decompress_mv, decompress_one_stage), inverse_MCTF, the estimate-mode forward (forward / forward_one_stage at
-inference).  Not implemented (raise NotImplementedError): the estimate-only branch of encode_one_stage
-(output_path=None; broken in the reference itself), training-mode forward.  me_downsample in
-{1, 2, 4, 8} is supported everywhere (motion estimated and coded at reduced resolution).
+inference), the estimate-only branch of encode_one_stage (output_path=None: forward_one_stage for luma and chroma; the
+reference's own version raises KeyError, SURVEY F3 — here it returns what it was meant to).  Not implemented (raise
+NotImplementedError): training-mode forward.  me_downsample in {1, 2, 4, 8} is supported everywhere (motion
+estimated and coded at reduced resolution).
 """
 import os
 import os.path as osp
@@ -172,14 +173,16 @@ class pMCTF(nn.Module):
 
     @torch.no_grad()
     def encode_stage_pairs(self, pairs, code_lt, dpb, output_paths, pic_width, pic_height, psize=128, stage_idx=0,
-                           q_index=0):
+                           q_index=0, chain_reset=()):
         """All pairs of one temporal stage in one call: pairs = [(ref_frame, cur_frame)], output_paths = ["k.bin"].
         Returns ([result dict per pair, exactly what encode_one_stage(skip_decoding=True) returns for it], dpb for a
         following call).  The motion codec runs pair after pair (its context is a chain, pMCTF_L.py:448-495); the
         temporal lifting and the spatial coders — 93 % of the work — run as ONE batch over the pairs, so every launch
         is len(pairs) times larger (the MI355X-side answer to the small, latency-bound subbands of the wavelet
         pyramid; 288 GB of HBM hold the larger activations easily).  Files, bits and tensors are identical to calling
-        encode_one_stage pair by pair (tests/test_gpu_engine.py::test_batched_stage_equals_pair_by_pair)."""
+        encode_one_stage pair by pair (tests/test_gpu_engine.py::test_batched_stage_equals_pair_by_pair).
+        chain_reset: indexes of pairs at which the motion context restarts from the empty one — the first pair of every
+        further closed GOP when the same stage of several GOPs is coded in one call (pmctf_gop.encode_gops_batched)."""
         eng = self.engine()
         dev = next(self.parameters()).device
         c = lambda t: t.to(dev).contiguous()
@@ -188,7 +191,10 @@ class pMCTF(nn.Module):
         P = len(pairs)
         jobs = [dict() for _ in range(P)]
         mvs = []
+        chain_reset = set(chain_reset)
         for i, ((ref_y, _), (cur_y, _)) in enumerate(pairs):
+            if i in chain_reset:
+                dpb = {"mv_feature": None, "ref_mv_y": None}
             mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index)
             jobs[i]["mv"] = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0),
                                              output_paths[i].replace(".bin", "_mv.bin"), keep)
@@ -265,6 +271,12 @@ class pMCTF(nn.Module):
             r["encoding_time"] = (time.time() - start) / P
         return results, dpb
 
+    @staticmethod
+    def dpb_shapes(height, width, me_downsample=1):
+        """logical NCHW shapes of the motion codec's context (mv_feature, ref_mv_y) for planes of height x width"""
+        h, w = height // me_downsample, width // me_downsample
+        return [(1, 64, h // 4, w // 4), (1, 64, h // 16, w // 16)]
+
     @torch.no_grad()
     def advance_dpb(self, ref_frame, cur_frame, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """The motion part of encode_one_stage only (pMCTF_L.py:448-495): returns the `dpb` the NEXT pair of the stage
@@ -322,12 +334,29 @@ class pMCTF(nn.Module):
 
     @torch.no_grad()
     def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
-                         psize=128, skip_decoding=False, stage_idx=0, q_index=0, me_downsample=1):
-        """Write-stream branch of pMCTF_L.py:525-637 for one frame pair."""
-        if output_path is None:
-            raise NotImplementedError("estimate-only branch (output_path=None) is not part of this build "
-                                      "(it raises KeyError in the reference as well)")
+                         psize=128, skip_decoding=False, stage_idx=0, q_index=0, me_downsample=1, on_dpb=None):
+        """Write-stream branch of pMCTF_L.py:525-637 for one frame pair.
+        Beyond the reference's signature (used by pmctf_dist's relay only): `dpb` may be a zero-argument callable that
+        delivers the context once the motion has been estimated, and `on_dpb(dpb)` is called with the NEXT pair's
+        context as soon as the motion codec has produced it, before the subbands are coded."""
         self._check_ds(me_downsample)
+        if output_path is None:
+            # Estimate-only branch (pMCTF_L.py:530-551): the same networks with Laplace / factorized bit estimates, no
+            # range coding.  The reference builds `dpb` from result["mv_feature"] / result["ref_mv_y"], keys that
+            # forward_one_stage does not return (KeyError, SURVEY F3); what it was meant to hand on is
+            # forward_one_stage's own "dpb", which is what is returned here.
+            if callable(dpb):
+                dpb = dpb()
+            ry = self.forward_one_stage(ref_frame[0], cur_frame[0], q_index, code_lt, dpb, stage_idx=stage_idx,
+                                        me_downsample=me_downsample)
+            rc = self.forward_one_stage(ref_frame[1], cur_frame[1], q_index, code_lt, dpb, mv_hat=ry["mv_hat"],
+                                        stage_idx=stage_idx, me_downsample=me_downsample)
+            if on_dpb is not None:
+                on_dpb(ry["dpb"])
+            return {"L_t": ry["L_t"], "H_t": ry["H_t"], "L_tc": rc["L_t"], "H_tc": rc["H_t"],
+                    "bit_L": ry["bit_L"] + rc["bit_L"] if code_lt else None, "bit_H": ry["bit_H"] + rc["bit_H"],
+                    "bit_Lc": rc["bit_L"] if code_lt else None, "bit_Hc": rc["bit_H"], "bit_ME": ry["bit_ME"],
+                    "mv_hat": ry["mv_hat"], "dpb": ry["dpb"], "decoding_time": 0, "encoding_time": 0}
         eng = self.engine()
         ref_y, ref_chroma = ref_frame
         cur_y, cur_chroma = cur_frame
@@ -336,9 +365,22 @@ class pMCTF(nn.Module):
         start = time.time()
         keep = eng.keep_streams
         mv_out = output_path.replace(".bin", "_mv.bin")
-        mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index, me_downsample=me_downsample)
+        if callable(dpb):
+            deliver, got = dpb, {}
+
+            def dpb():
+                got["dpb"] = deliver()
+                return got["dpb"]
+            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index,
+                                 me_downsample=me_downsample)
+            dpb = got["dpb"]
+        else:
+            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index,
+                                 me_downsample=me_downsample)
         jobs = {"mv": eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0), mv_out, keep)}
         mv_hat = mv["mv_hat"]
+        if on_dpb is not None:
+            on_dpb({"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)})
         base = osp.basename(output_path)
         file_name_c = output_path.replace(".bin", "_C_main.bin")
         ry, cy, rc, cc = c(ref_y), c(cur_y), c(ref_chroma), c(cur_chroma)

@@ -62,6 +62,47 @@ def encode_gop_batched(codec, frames, pic_height, pic_width, q_index, bin_folder
     return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
 
 
+def encode_gops_batched(codec, gops, pic_height, pic_width, q_index, bin_folders, psize=128):
+    """K closed GOPs at once: stage s of ALL of them goes to the codec in one encode_stage_pairs call (the GOPs are
+    independent units, test_pMCTF_flex.py:131-141, and use the same coder weights), so the late stages — 2 and 1 pairs
+    per GOP — are batched K-fold as well.  The motion context restarts at every GOP boundary (chain_reset); each GOP's
+    files go to its own folder.  Returns one encode_gop-style dict per GOP; files, bits and tensors are identical to
+    coding the GOPs one after the other."""
+    K = len(gops)
+    gop = len(gops[0])
+    stages = int(round(math.log2(gop)))
+    assert 2 ** stages == gop and gop >= 2 and all(len(g) == gop for g in gops) and len(bin_folders) == K
+    outs = [{"bits": [None] * gop, "bits_mv": [None] * gop, "frames_coded": [None] * gop, "results": [],
+             "stages": stages} for _ in range(K)]
+    num_frames = gop
+    for stage_idx in range(stages):
+        num_frames //= 2
+        step = 2 ** stage_idx
+        code_lt = (stage_idx + 1) == stages
+        me_num = min(codec.num_me_stages - 1, stage_idx)
+        idx = [(g * 2 * step, g * 2 * step + step) for g in range(num_frames)]
+        pairs, paths = [], []
+        for k in range(K):
+            src = gops[k] if stage_idx == 0 else [f[:2] for f in outs[k]["frames_coded"]]
+            pairs += [(src[a], src[b]) for a, b in idx]
+            paths += [os.path.join(bin_folders[k], f"{b}.bin") for _, b in idx]
+        rs, _ = codec.encode_stage_pairs(pairs, code_lt, {"mv_feature": None, "ref_mv_y": None}, paths,
+                                         pic_width=pic_width, pic_height=pic_height, psize=psize, stage_idx=me_num,
+                                         q_index=q_index, chain_reset=[k * num_frames for k in range(1, K)])
+        for k in range(K):
+            o = outs[k]
+            for (i_ref, i_cur), r in zip(idx, rs[k * num_frames:(k + 1) * num_frames]):
+                o["frames_coded"][i_ref] = [r["L_t"], r["L_tc"], None]
+                o["frames_coded"][i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
+                o["bits"][i_cur] = float(r["bit_H"] + r["bit_ME"])
+                o["bits_mv"][i_cur] = float(r["bit_ME"])
+                if code_lt:
+                    o["bits"][i_ref] = float(r["bit_L"])
+                    o["bits_mv"][i_ref] = 0.0
+                o["results"].append(r)
+    return outs
+
+
 def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_decoding=True, psize=128,
                on_pair=None, me_downsample=1):
     """frames: list (len = GOP size, power of two) of [Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] padded tensors.
@@ -92,7 +133,8 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
                 assert mv_r is None and mv_c is None
             code_lt = (stage_idx + 1) == stages
             me_num = min(codec.num_me_stages - 1, stage_idx)
-            bin_path = os.path.join(bin_folder, f"{i_cur}.bin")
+            # bin_folder None: the estimate-only branch of encode_one_stage (test_pMCTF_CA.py:153-154)
+            bin_path = os.path.join(bin_folder, f"{i_cur}.bin") if bin_folder is not None else None
             r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur], output_path=bin_path,
                                        pic_height=pic_height, pic_width=pic_width, stage_idx=me_num,
                                        code_lt=code_lt, psize=psize, skip_decoding=skip_decoding, dpb=dpb,
@@ -111,8 +153,10 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
     return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
 
 
-def decode_gop(codec, frames_coded):
-    """Temporal synthesis, test_pMCTF_flex.py:268-291.  Modifies and returns frames_coded."""
+def decode_gop(codec, frames_coded, luma_stage0=False):
+    """Temporal synthesis, test_pMCTF_flex.py:268-291.  Modifies and returns frames_coded.
+    luma_stage0: the content-adaptive harness's variant, which reconstructs luma with stage 0's lifting filters at every
+    stage (inverse_MCTF without stage_idx, test_pMCTF_CA.py:239)."""
     gop = len(frames_coded)
     stages = int(round(math.log2(gop)))
     num_frames = 1
@@ -126,7 +170,7 @@ def decode_gop(codec, frames_coded):
             H_t, H_tc, mv_hat = frames_coded[i_ref + step]
             assert mv_ref is None
             me_num = min(codec.num_me_stages - 1, stage_idx)
-            ref, cur = codec.inverse_MCTF(L_t, H_t, mv_hat, stage_idx=me_num)
+            ref, cur = codec.inverse_MCTF(L_t, H_t, mv_hat, stage_idx=0 if luma_stage0 else me_num)
             ref_c, cur_c = codec.inverse_MCTF(L_tc, H_tc, mv_hat, stage_idx=me_num, downscale=True)
             frames_coded[i_ref] = [ref, ref_c, None]
             frames_coded[i_ref + step] = [cur, cur_c, None]

@@ -63,6 +63,8 @@ static void pm_parallel_for(long n, long chunk, pm_job_fn fn, void *ctx) {
  *     for ky: for kx: for ci in chunk: acc = fmaf(x, w, acc)   (out-of-image taps skipped == +0)
  * ------------------------------------------------------------------------- */
 #define PM_XB 32 /* output columns kept in registers */
+static int pm_conv_order = 0;
+void pm_set_conv_order(int o) { pm_conv_order = o; }
 typedef struct {
     const float *xp, *w, *bias; float *y;
     int N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc;
@@ -81,7 +83,49 @@ static void pm_conv_job(long job, void *vctx) {
     const float b = c->bias ? c->bias[co] : 0.0f;
     for (int xb = 0; xb < Wo; xb += PM_XB) {
         float acc[PM_XB];
-        if (stride == 1) {
+        if (stride == 1 && pm_conv_order == 1) {
+            /* EXPERIMENT: oneDNN jit:avx512_core order — per 16-channel block a chain from zero, block sums added to
+             * the running output, bias added after the first block */
+            __m256 t0 = _mm256_setzero_ps(), t1 = t0, t2 = t0, t3 = t0;
+            for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
+                const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
+                __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        for (int ci = c0; ci < c1; ++ci) {
+                            const __m256 wv = _mm256_set1_ps(w[(((long)co * Cin + ci) * KH + ky) * KW + kx]);
+                            const float *row = xp + (((long)n * Hc + oy + ky) * Cin + ci) * Wc + xb + kx;
+                            a0 = _mm256_fmadd_ps(_mm256_loadu_ps(row), wv, a0);
+                            a1 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 8), wv, a1);
+                            a2 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 16), wv, a2);
+                            a3 = _mm256_fmadd_ps(_mm256_loadu_ps(row + 24), wv, a3);
+                        }
+                if (c0 == 0) {
+                    const __m256 bv = _mm256_set1_ps(b);
+                    t0 = _mm256_add_ps(a0, bv); t1 = _mm256_add_ps(a1, bv); t2 = _mm256_add_ps(a2, bv); t3 = _mm256_add_ps(a3, bv);
+                } else {
+                    t0 = _mm256_add_ps(t0, a0); t1 = _mm256_add_ps(t1, a1); t2 = _mm256_add_ps(t2, a2); t3 = _mm256_add_ps(t3, a3);
+                }
+            }
+            _mm256_storeu_ps(acc, t0); _mm256_storeu_ps(acc + 8, t1);
+            _mm256_storeu_ps(acc + 16, t2); _mm256_storeu_ps(acc + 24, t3);
+        } else if (pm_conv_order == 1) {
+            float tot[PM_XB];
+            for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
+                const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
+                for (int j = 0; j < PM_XB; ++j) acc[j] = 0.0f;
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        for (int ci = c0; ci < c1; ++ci) {
+                            const float wv = w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+                            const float *restrict row = xp + (((long)n * Hc + (long)oy * stride + ky) * Cin + ci) * Wc +
+                                                        (long)xb * stride + kx;
+                            for (int j = 0; j < PM_XB; ++j) acc[j] = fmaf(row[(long)j * stride], wv, acc[j]);
+                        }
+                for (int j = 0; j < PM_XB; ++j) tot[j] = c0 == 0 ? acc[j] + b : tot[j] + acc[j];
+            }
+            for (int j = 0; j < PM_XB; ++j) acc[j] = tot[j];
+        } else if (stride == 1) {
             /* 4 x 8 lanes held in registers; _mm256_fmadd_ps is the same single-rounding fmaf per lane */
             __m256 a0 = _mm256_set1_ps(b), a1 = a0, a2 = a0, a3 = a0;
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {

@@ -5,6 +5,8 @@
  *   reverse-order flush              pMCTF/cpp/rans/rans.cpp:141-168
  *   decoder                          pMCTF/cpp/rans/rans.cpp:265-331
  *   1-byte stream header (1 stream)  pMCTF/cpp/py_rans/py_rans.cpp:74-119,133-164
+ *   N-part container (pm_rans_menc / pm_rans_mdec): per-push partition py_rans.cpp:52-65,196-209,
+ *   flag byte + 2/4-byte part sizes py_rans.cpp:74-119, parsing :133-164
  *   pmf -> quantised CDF             pMCTF/cpp/ops/ops.cpp:24-82
  * The 64-bit rANS state primitives come from a dependency that is NOT in
  * /root/reference: rygorous/ryg_rans @ c9d162d996fd600315af9ae8eb89d832576cb32d,
@@ -12,7 +14,7 @@
  * Its published algorithm is restated below (state in [2^31, 2^63), 32-bit
  * little-endian renormalisation words, encoder writes backwards).  Those
  * primitives are pinned only through the end-to-end known-answer stream in
- * SURVEY.md §8c (tests/test_oracle_rans.py).
+ * SURVEY.md §8c (tests/test_oracle_kat.py::test_rans_known_answer_stream_and_roundtrip).
  */
 #include <math.h>
 #include <stdint.h>
@@ -185,6 +187,115 @@ void pm_rans_dec_decode_stream(pm_rans_dec *d, const int16_t *indexes, long n, c
         }
         out[i] = (int16_t)(value + offset);
     }
+}
+
+/* ------------------- N-part container (stream_part > 1) ------------------ */
+/* py_rans.cpp: RansEncoder(multiThread, streamPart) holds streamPart RansEncoderLib objects; EVERY
+ * encode_with_indexes call cuts its symbols into streamPart runs of n/streamPart (the last takes the
+ * remainder, :52-65); get_encoded_stream (:74-119) writes  flag = ((N-1)<<4) | (sizes are 2-byte ? 1 : 0),
+ * then the sizes of the first N-1 part streams (2 bytes each if the largest of THEM is <= 65535, else 4),
+ * then the part streams back to back.  The decoder (:133-164, :196-224) undoes exactly that. */
+typedef struct pm_rans_menc { int parts; pm_rans_enc **e; uint8_t *stream; long stream_len; } pm_rans_menc;
+
+pm_rans_menc *pm_rans_menc_new(int parts) {
+    if (parts < 1 || parts > 16) return NULL;
+    pm_rans_menc *m = (pm_rans_menc *)calloc(1, sizeof(pm_rans_menc));
+    m->parts = parts;
+    m->e = (pm_rans_enc **)calloc((size_t)parts, sizeof(pm_rans_enc *));
+    for (int i = 0; i < parts; ++i) m->e[i] = pm_rans_enc_new();
+    return m;
+}
+void pm_rans_menc_free(pm_rans_menc *m) {
+    if (!m) return;
+    for (int i = 0; i < m->parts; ++i) pm_rans_enc_free(m->e[i]);
+    free(m->e); free(m->stream); free(m);
+}
+void pm_rans_menc_reset(pm_rans_menc *m) { for (int i = 0; i < m->parts; ++i) pm_rans_enc_reset(m->e[i]); }
+void pm_rans_menc_encode_with_indexes(pm_rans_menc *m, const int16_t *symbols, const int16_t *indexes, long n,
+                                      const int32_t *cdfs, int cdf_cols, const int32_t *cdf_sizes,
+                                      const int32_t *offsets) {
+    const long each = n / m->parts, last = n - each * (m->parts - 1);
+    for (int i = 0; i < m->parts; ++i)
+        pm_rans_enc_encode_with_indexes(m->e[i], symbols + i * each, indexes + i * each,
+                                        i < m->parts - 1 ? each : last, cdfs, cdf_cols, cdf_sizes, offsets);
+}
+void pm_rans_menc_flush(pm_rans_menc *m) {
+    long total = 0, maximum = 0;
+    for (int i = 0; i < m->parts; ++i) {
+        pm_rans_enc_flush(m->e[i]);                  /* e->stream = 1 flag byte + payload */
+        const long nb = m->e[i]->stream_len - 1;
+        if (i < m->parts - 1 && nb > maximum) maximum = nb;
+        total += nb;
+    }
+    const int hdr = maximum > 65535 ? 4 : 2;
+    const long overhead = 1 + (long)(m->parts - 1) * hdr;
+    free(m->stream);
+    m->stream = (uint8_t *)malloc((size_t)(total + overhead));
+    m->stream[0] = (uint8_t)(((m->parts - 1) << 4) + (hdr == 2 ? 1 : 0));
+    for (int i = 0; i < m->parts - 1; ++i) {
+        const long nb = m->e[i]->stream_len - 1;
+        if (hdr == 2) { const uint16_t v = (uint16_t)nb; memcpy(m->stream + 1 + 2 * i, &v, 2); }
+        else { const uint32_t v = (uint32_t)nb; memcpy(m->stream + 1 + 4 * i, &v, 4); }
+    }
+    long o = overhead;
+    for (int i = 0; i < m->parts; ++i) {
+        const long nb = m->e[i]->stream_len - 1;
+        memcpy(m->stream + o, m->e[i]->stream + 1, (size_t)nb);
+        o += nb;
+    }
+    m->stream_len = total + overhead;
+}
+long pm_rans_menc_stream_size(const pm_rans_menc *m) { return m->stream_len; }
+void pm_rans_menc_get_stream(const pm_rans_menc *m, uint8_t *dst) { memcpy(dst, m->stream, (size_t)m->stream_len); }
+
+typedef struct pm_rans_mdec { int parts; pm_rans_dec **d; } pm_rans_mdec;
+pm_rans_mdec *pm_rans_mdec_new(int parts) {
+    if (parts < 1 || parts > 16) return NULL;
+    pm_rans_mdec *m = (pm_rans_mdec *)calloc(1, sizeof(pm_rans_mdec));
+    m->parts = parts;
+    m->d = (pm_rans_dec **)calloc((size_t)parts, sizeof(pm_rans_dec *));
+    for (int i = 0; i < parts; ++i) m->d[i] = pm_rans_dec_new();
+    return m;
+}
+void pm_rans_mdec_free(pm_rans_mdec *m) {
+    if (!m) return;
+    for (int i = 0; i < m->parts; ++i) pm_rans_dec_free(m->d[i]);
+    free(m->d); free(m);
+}
+/* py_rans.cpp:133-164 */
+int pm_rans_mdec_set_stream(pm_rans_mdec *m, const uint8_t *bytes, long n) {
+    if (n < 1) return -1;
+    const int streams = (bytes[0] >> 4) + 1;
+    const int hdr = (bytes[0] & 0x0f) == 1 ? 2 : 4;
+    if (streams != m->parts) return -1;
+    long offset = 1, sizes[16], total = 0;
+    for (int i = 0; i < streams - 1; ++i) {
+        if (offset + hdr > n) return -1;
+        if (hdr == 2) { uint16_t v; memcpy(&v, bytes + offset, 2); sizes[i] = v; }
+        else { uint32_t v; memcpy(&v, bytes + offset, 4); sizes[i] = v; }
+        offset += hdr; total += sizes[i];
+    }
+    sizes[streams - 1] = n - offset - total;
+    for (int i = 0; i < streams; ++i) {
+        if (sizes[i] < 8 || offset + sizes[i] > n) return -1;
+        /* pm_rans_dec_set_stream wants the single-stream framing: one flag byte in front of the payload */
+        uint8_t *tmp = (uint8_t *)malloc((size_t)sizes[i] + 1);
+        tmp[0] = 0x01;
+        memcpy(tmp + 1, bytes + offset, (size_t)sizes[i]);
+        const int rc = pm_rans_dec_set_stream(m->d[i], tmp, sizes[i] + 1);
+        free(tmp);
+        if (rc != 0) return -1;
+        offset += sizes[i];
+    }
+    return 0;
+}
+/* py_rans.cpp:196-224: the index array of ONE decode_stream call is cut like the symbols of one push */
+void pm_rans_mdec_decode_stream(pm_rans_mdec *m, const int16_t *indexes, long n, const int32_t *cdfs, int cdf_cols,
+                                const int32_t *cdf_sizes, const int32_t *offsets, int16_t *out) {
+    const long each = n / m->parts, last = n - each * (m->parts - 1);
+    for (int i = 0; i < m->parts; ++i)
+        pm_rans_dec_decode_stream(m->d[i], indexes + i * each, i < m->parts - 1 ? each : last, cdfs, cdf_cols,
+                                  cdf_sizes, offsets, out + i * each);
 }
 
 /* ops.cpp:24-82.  cdf has n+1 entries.  Returns 0, or -1 if no frequency can be stolen. */

@@ -54,6 +54,21 @@ def lib():
     L.pm_rans_dec_set_stream.argtypes = [C.c_void_p, u8p, C.c_long]
     L.pm_rans_dec_set_stream.restype = C.c_int
     L.pm_rans_dec_decode_stream.argtypes = [C.c_void_p, i16p, C.c_long, i32p, C.c_int, i32p, i32p, i16p]
+    L.pm_rans_menc_new.restype = C.c_void_p
+    L.pm_rans_menc_new.argtypes = [C.c_int]
+    L.pm_rans_menc_free.argtypes = [C.c_void_p]
+    L.pm_rans_menc_reset.argtypes = [C.c_void_p]
+    L.pm_rans_menc_encode_with_indexes.argtypes = [C.c_void_p, i16p, i16p, C.c_long, i32p, C.c_int, i32p, i32p]
+    L.pm_rans_menc_flush.argtypes = [C.c_void_p]
+    L.pm_rans_menc_stream_size.argtypes = [C.c_void_p]
+    L.pm_rans_menc_stream_size.restype = C.c_long
+    L.pm_rans_menc_get_stream.argtypes = [C.c_void_p, u8p]
+    L.pm_rans_mdec_new.restype = C.c_void_p
+    L.pm_rans_mdec_new.argtypes = [C.c_int]
+    L.pm_rans_mdec_free.argtypes = [C.c_void_p]
+    L.pm_rans_mdec_set_stream.argtypes = [C.c_void_p, u8p, C.c_long]
+    L.pm_rans_mdec_set_stream.restype = C.c_int
+    L.pm_rans_mdec_decode_stream.argtypes = [C.c_void_p, i16p, C.c_long, i32p, C.c_int, i32p, i32p, i16p]
     L.pm_pmf_to_quantized_cdf.argtypes = [f32p, C.c_int, C.c_int, u32p]
     L.pm_pmf_to_quantized_cdf.restype = C.c_int
     _lib = L
@@ -218,4 +233,63 @@ class RansDecoder:
         out = np.empty(indexes.size, np.int16)
         lib().pm_rans_dec_decode_stream(self._h, indexes, indexes.size, cdfs, cdfs.shape[1],
                                         _c(cdf_sizes, np.int32), _c(offsets, np.int32), out)
+        return out
+
+
+class RansEncoderParts:
+    """MLCodec_rans.RansEncoder(False, parts) — the N-part container of py_rans.cpp:29-119 (stream_part > 1)."""
+
+    def __init__(self, parts):
+        self._h = lib().pm_rans_menc_new(parts)
+        if not self._h:
+            raise ValueError("parts must be 1..16")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.pm_rans_menc_free(self._h)
+            self._h = None
+
+    def reset(self):
+        lib().pm_rans_menc_reset(self._h)
+
+    def encode_with_indexes(self, symbols, indexes, cdfs, cdf_sizes, offsets):
+        symbols, indexes = _c(symbols, np.int16).reshape(-1), _c(indexes, np.int16).reshape(-1)
+        cdfs = _c(cdfs, np.int32)
+        lib().pm_rans_menc_encode_with_indexes(self._h, symbols, indexes, symbols.size, cdfs, cdfs.shape[1],
+                                               _c(cdf_sizes, np.int32), _c(offsets, np.int32))
+
+    def flush(self):
+        lib().pm_rans_menc_flush(self._h)
+
+    def get_encoded_stream(self):
+        n = lib().pm_rans_menc_stream_size(self._h)
+        out = np.empty(n, np.uint8)
+        lib().pm_rans_menc_get_stream(self._h, out)
+        return out
+
+
+class RansDecoderParts:
+    """MLCodec_rans.RansDecoder(parts), py_rans.cpp:127-224."""
+
+    def __init__(self, parts):
+        self._h = lib().pm_rans_mdec_new(parts)
+        if not self._h:
+            raise ValueError("parts must be 1..16")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.pm_rans_mdec_free(self._h)
+            self._h = None
+
+    def set_stream(self, stream):
+        stream = _c(np.frombuffer(bytes(stream), dtype=np.uint8), np.uint8)
+        if lib().pm_rans_mdec_set_stream(self._h, stream, stream.size) != 0:
+            raise ValueError("bad stream")
+
+    def decode_stream(self, indexes, cdfs, cdf_sizes, offsets):
+        indexes = _c(indexes, np.int16).reshape(-1)
+        cdfs = _c(cdfs, np.int32)
+        out = np.empty(indexes.size, np.int16)
+        lib().pm_rans_mdec_decode_stream(self._h, indexes, indexes.size, cdfs, cdfs.shape[1],
+                                         _c(cdf_sizes, np.int32), _c(offsets, np.int32), out)
         return out

@@ -1024,6 +1024,21 @@ class _EstimateMixin:
         return ret
 
 
+    def estimate_one_stage(self, ref_frame, cur_frame, code_lt, dpb, stage_idx=0, q_index=0, me_downsample=1):
+        """the estimate-only branch of encode_one_stage (pMCTF_L.py:530-551): forward_one_stage for luma, then chroma
+        with the luma motion.  The reference reads result["mv_feature"] / result["ref_mv_y"] here, keys that
+        forward_one_stage does not return (KeyError upstream); the context it was meant to hand on is
+        forward_one_stage's "dpb"."""
+        ry = self.forward_one_stage(ref_frame[0], cur_frame[0], q_index, code_lt, dpb, stage_idx=stage_idx,
+                                    me_downsample=me_downsample)
+        rc = self.forward_one_stage(ref_frame[1], cur_frame[1], q_index, code_lt, dpb, mv_hat=ry["mv_hat"],
+                                    stage_idx=stage_idx, me_downsample=me_downsample)
+        return {"L_t": ry["L_t"], "H_t": ry["H_t"], "L_tc": rc["L_t"], "H_tc": rc["H_t"],
+                "bit_L": ry["bit_L"] + rc["bit_L"] if code_lt else None, "bit_H": ry["bit_H"] + rc["bit_H"],
+                "bit_Lc": rc["bit_L"] if code_lt else None, "bit_Hc": rc["bit_H"], "bit_ME": ry["bit_ME"],
+                "mv_hat": ry["mv_hat"], "dpb": ry["dpb"], "decoding_time": 0, "encoding_time": 0}
+
+
 for _n, _f in list(vars(_EstimateMixin).items()):
     if callable(_f) and not _n.startswith("__"):
         setattr(Oracle, _n, _f)

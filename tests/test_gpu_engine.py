@@ -463,64 +463,112 @@ def test_gop4_960x544_vs_reference(setup):
     assert same >= 9 and diff <= 2, (same, diff)
 
 
-def _headline_fixtures():
-    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    return [q for q in (3, 20, 0)
-            if os.path.exists(os.path.join(d, "reference_1920x1080_gop16_me4%s_digest.npz" % ("" if q == 3 else f"_q{q}")))]
+def _digest_path(gop, q_index):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                        "reference_1920x1080_gop%d_me4%s_digest.npz" % (gop, "" if q_index == 3 else f"_q{q_index}"))
 
 
-@pytest.mark.parametrize("q_index", _headline_fixtures())
-def test_headline_config_1080p_gop16_vs_reference(cuda, q_index):
-    """BASELINE's headline configuration itself — 1920x1080, GOP 16, q_index 3, four ME stages, full encode with
-    bitstream write and PSNR — against digests of what the REAL reference produced for the same synthetic sequence and
-    weights on the CPU (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4, about half an
-    hour of CPU per rate point; q_index 3 is the benchmark's point, 20 and 0 the ends of the RD sweep of configs[3]):
-    bits of every frame identical (bpp bit-exact), PSNR within 1e-4 dB."""
+# BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
+# benchmark's own point (GOP 16, q_index 3): every one has a digest of the REAL reference's CPU run
+# (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop G --me_stages 4 --q_index q; 20-45 min of CPU each)
+HEADLINE_CONFIGS = [(g, q) for g, q in ((16, 3), (8, 3), (16, 0), (16, 4), (16, 8), (16, 12), (16, 16), (16, 20))
+                    if os.path.exists(_digest_path(g, q))]
+# Where PM-F32 and ATen round a conv sum differently and the difference lands on a decision boundary, a symbol or a CDF
+# row flips; a flip can move a stream by one 32-bit rANS word.  What was observed on this sequence, per configuration
+# (per-frame bit deltas product - reference, max |PSNR error| in dB): pinned exactly, so any drift fails.
+HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline_pins.json")
+_headline_cache = {}
+
+
+def _headline_run(gop, q_index):
     import hashlib
     import pmctf_gop
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_1920x1080_gop16_me4%s_digest.npz" % ("" if q_index == 3 else f"_q{q_index}"))
-    g = np.load(path)
+    key = (gop, q_index)
+    if key in _headline_cache:
+        return _headline_cache[key]
+    g = np.load(_digest_path(gop, q_index))
     net, _ = product_model(4)
     net.engine().keep_streams = True
     w, h = 1920, 1080
-    fr = frames(w, h, 16, device="cuda")
+    fr = frames(w, h, gop, device="cuda")
     with tempfile.TemporaryDirectory() as td:
         enc = pmctf_gop.encode_gop(net, fr, h, w, q_index, td)
         rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
         ps = pmctf_gop.gop_psnr(rec, fr, h, w)
-    bpp = sum(enc["bits"]) / (16 * w * h)
-    bpp_ref = float(g["gop.bits"].sum()) / (16 * w * h)
-    psnr_err = np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max()
     same = diff = 0
+    lengths_equal = True
     for i, r in enumerate(enc["results"]):
         cur = int(g[f"gop.pair{i}.meta"][2])
-        for name, key in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin"),
-                          ("L", "0_main.bin"), ("Lc", "0_C_main.bin")):
-            k = f"gop.pair{i}.filesha1.{key}"
+        for name, fkey in (("mv", f"{cur}_mv.bin"), ("H", f"{cur}.bin"), ("Hc", f"{cur}_C_main.bin"),
+                           ("L", "0_main.bin"), ("Lc", "0_C_main.bin")):
+            k = f"gop.pair{i}.filesha1.{fkey}"
             if name in r["files"] and k in g.files:
+                lengths_equal &= len(r["files"][name]) == int(g[k.replace("filesha1", "filelen")])
                 if hashlib.sha1(r["files"][name]).digest() == g[k].tobytes():
                     same += 1
                 else:
                     diff += 1
-    print(f"1080p GOP-16 q_index {q_index}: bpp {bpp:.6f} (reference {bpp_ref:.6f}), max PSNR error {psnr_err:.2e} dB, "
-          f"{same} of {same + diff} files byte-identical")
-    if q_index == 3:
-        # the benchmark's rate point: the north star's bar, exactly
-        assert enc["bits"] == g["gop.bits"].tolist(), "bits per frame differ from the reference"
-        assert enc["bits_mv"] == g["gop.bits_mv"].tolist()
-        assert psnr_err < 1e-4
-        # every file has the reference's length; where PM-F32 and ATen round a conv sum differently and a tie flips a
-        # symbol, the bytes inside differ (13 of 47 files on this sequence) — reported above, and bounded here
-        assert same + diff == 47 and same >= 30
-    else:
-        # ends of the RD sweep: the same effect can move a stream by one 32-bit rANS word (observed: q_index 20, two frames
-        # of 16 are 32 bits longer out of 98.5 Mbit, PSNR off by 1.3e-4 dB).  Stated as measured, bounded here.
-        dbits = np.abs(np.array(enc["bits"]) - g["gop.bits"])
-        print("   per-frame bit differences:", dbits.tolist())
-        assert dbits.max() <= 64 and dbits.sum() <= 1e-6 * g["gop.bits"].sum()
-        assert psnr_err < 5e-4
-        assert same + diff == 47
+    out = {"bits": enc["bits"], "bits_mv": enc["bits_mv"], "ref_bits": g["gop.bits"].tolist(),
+           "ref_bits_mv": g["gop.bits_mv"].tolist(),
+           "dbits": (np.array(enc["bits"]) - g["gop.bits"]).astype(np.int64).tolist(),
+           "psnr_err": float(np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max()),
+           "same": same, "diff": diff, "lengths_equal": bool(lengths_equal),
+           "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
+    print(f"1080p GOP-{gop} q_index {q_index}: bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
+          f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
+    d = os.environ.get("PMCTF_HEADLINE_REPORT")
+    if d:       # builder's measuring run: collect what the pins file is written from
+        import json
+        os.makedirs(d, exist_ok=True)
+        json.dump({k: out[k] for k in ("dbits", "psnr_err", "same", "diff", "lengths_equal", "bpp", "bpp_ref")},
+                  open(os.path.join(d, f"gop{gop}_q{q_index}.json"), "w"))
+    _headline_cache[key] = out
+    del enc, rec, fr
+    torch.cuda.empty_cache()
+    return out
+
+
+def _strict_params():
+    import json
+    pins = json.load(open(HEADLINE_PINS_FILE)) if os.path.exists(HEADLINE_PINS_FILE) else {}
+    out = []
+    for g, q in HEADLINE_CONFIGS:
+        pin = pins.get(f"gop{g}_q{q}")
+        marks = []
+        if pin is not None and (any(pin["dbits"]) or pin["psnr_err"] >= 1e-4):
+            marks = [pytest.mark.xfail(strict=True, reason=f"measured: per-frame bit deltas {pin['dbits']}, max PSNR error "
+                                                           f"{pin['psnr_err']:.2e} dB (last-bit rounding of conv sums, "
+                                                           f"PM-F32 vs ATen; pinned exactly by the test below)")]
+        out.append(pytest.param(g, q, marks=marks, id=f"gop{g}-q{q}"))
+    return out
+
+
+@pytest.mark.parametrize("gop,q_index", _strict_params())
+def test_headline_configs_1080p_vs_reference(cuda, gop, q_index):
+    """The north star's bar, exactly, at full size against the REAL reference's CPU run of the same synthetic sequence
+    and weights: bits of every frame identical (bpp bit-exact), PSNR within 1e-4 dB — for BASELINE configs[2] (GOP 8),
+    every point of configs[3]'s RD sweep (GOP 16, q_index 0/4/8/12/16/20) and the benchmark's point (GOP 16, q_index 3).
+    A configuration that misses the bar is an expected failure carrying the measured numbers, never a widened bound."""
+    r = _headline_run(gop, q_index)
+    assert r["same"] + r["diff"] == 3 * (gop - 1) + 2
+    assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
+    assert r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+    assert r["lengths_equal"]
+
+
+@pytest.mark.parametrize("gop,q_index", HEADLINE_CONFIGS, ids=[f"gop{g}-q{q}" for g, q in HEADLINE_CONFIGS])
+def test_headline_configs_pinned_deviation(cuda, gop, q_index):
+    """Regression pin of what was measured against the reference for every configuration: the exact per-frame bit deltas,
+    the PSNR error (the arithmetic is deterministic, so it reproduces to the last digit) and the number of files whose
+    bytes differ at equal length."""
+    import json
+    pins = json.load(open(HEADLINE_PINS_FILE))
+    pin = pins[f"gop{gop}_q{q_index}"]
+    r = _headline_run(gop, q_index)
+    assert r["dbits"] == pin["dbits"]
+    assert abs(r["psnr_err"] - pin["psnr_err"]) < 1e-9
+    assert (r["same"], r["diff"]) == (pin["same"], pin["diff"])
 
 
 def test_gop_with_reduced_resolution_motion(setup):
@@ -572,18 +620,18 @@ def test_batched_stage_equals_pair_by_pair(cuda):
                 np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
 
 
-def test_headline_config_stage_batched_vs_reference(cuda):
-    """The schedule bench.py measures by default (pairs of a temporal stage as one batch) on the headline configuration,
-    against the real reference's digests: bits of every frame identical, PSNR within 1e-4 dB, and the very same files
-    as the pair-by-pair schedule."""
+@pytest.mark.parametrize("gop", [16, 8])
+def test_headline_config_stage_batched_vs_reference(cuda, gop):
+    """The stage-batched schedule (pairs of a temporal stage as one batch; bench.py's auxiliary figure) on the headline
+    configuration and on BASELINE configs[2] (GOP 8), against the real reference's digests: bits of every frame
+    identical, PSNR within 1e-4 dB, and the very same files as the pair-by-pair schedule."""
     import hashlib
     import pmctf_gop
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                             "reference_1920x1080_gop16_me4_digest.npz"))
+    g = np.load(_digest_path(gop, 3))
     net, _ = product_model(4)
     net.engine().keep_streams = True
     w, h = 1920, 1080
-    fr = frames(w, h, 16, device="cuda")
+    fr = frames(w, h, gop, device="cuda")
     with tempfile.TemporaryDirectory() as td:
         enc = pmctf_gop.encode_gop_batched(net, fr, h, w, 3, td)
         batched = {n: hashlib.sha1(open(os.path.join(td, n), "rb").read()).hexdigest() for n in sorted(os.listdir(td))}
@@ -595,7 +643,7 @@ def test_headline_config_stage_batched_vs_reference(cuda):
     with tempfile.TemporaryDirectory() as td:
         pmctf_gop.encode_gop(net, fr, h, w, 3, td)
         paired = {n: hashlib.sha1(open(os.path.join(td, n), "rb").read()).hexdigest() for n in sorted(os.listdir(td))}
-    assert batched == paired and len(batched) == 47
+    assert batched == paired and len(batched) == 3 * (gop - 1) + 2
 
 
 def test_bench_contract_small_run(cuda):
@@ -638,3 +686,256 @@ def test_batched_schedule_other_gop_sizes(cuda, gop, size):
     for p, q in zip(a["frames_coded"], b["frames_coded"]):
         for x, y in zip(p, q):
             assert (x is None and y is None) or torch.equal(x, y)
+
+
+def test_ll_params_and_conv_lstm_context_bitexact(setup):
+    """§8 a11 / a13 on their own: the LL subband's masked-conv parameter network and the conv-LSTM subband context
+    (three cells, the init_sequential quirk of a 1-channel LSTM3 cell state, the nearest-x2 + conv state upsampling after
+    an `hh` subband) against the oracle, tensor by tensor."""
+    net, orc = setup
+    eng = net.engine()
+    g = golden()
+    ll = torch.round(torch.from_numpy(g["unit.dwt.ll"])[:, :, :16, :16].contiguous() * 3.0)
+    p = eng.context_fusion_ll("hp_coder", ll.cuda())
+    op = orc.context_fusion_ll("hp_coder", ll)
+    assert_same(p.permute(0, 3, 1, 2), op, "LL parameters (scale, mean)")
+    # context: LL at level 3, then lh/hl/hh of level 3 (upsampling of all six states after hh), then lh of level 2
+    st = eng.ctx_init(1, 16, 16)
+    orc.ctx_init((1, 1, 16, 16))
+    rng = np.random.default_rng(5)
+    seq = [("ll", 3, 16), ("lh", 3, 16), ("hl", 3, 16), ("hh", 3, 16), ("lh", 2, 32)]
+    for name, lvl, n in seq:
+        sb = torch.from_numpy(rng.normal(0, 4, (1, 1, n, n)).astype(np.float32))
+        c = eng.ctx_forward_one_subband("hp_coder", st, sb.cuda(), name, lvl)
+        oc = orc.ctx_forward_one_subband("hp_coder", sb, name, lvl)
+        assert_same(c.permute(0, 3, 1, 2), oc, f"context after {name}{lvl}")
+        for key, ost in (("l1", orc.l1), ("l2", orc.l2), ("l3", orc.l3)):
+            assert_same(st[key][0].permute(0, 3, 1, 2), ost[0], f"{key} hidden after {name}{lvl}")
+            assert_same(st[key][1].permute(0, 3, 1, 2), ost[1], f"{key} cell after {name}{lvl}")
+
+
+def test_advance_dpb_equals_encode_one_stage_dpb(cuda):
+    """pMCTF.advance_dpb (the motion part of a pair only) hands on exactly the `dpb` that encode_one_stage returns —
+    what pair-level sharding rests on.  Two chained pairs, second motion model (stage_idx 1)."""
+    net, _ = product_model(2)
+    fr = frames(W, H, 4, device="cuda", seed=17)
+    dpb0 = {"mv_feature": None, "ref_mv_y": None}
+    with tempfile.TemporaryDirectory() as td:
+        for stage_idx in (0, 1):
+            r1 = net.encode_one_stage(fr[0], fr[1], False, dpb0, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                      pic_height=H, skip_decoding=True, stage_idx=stage_idx, q_index=3)
+            a1 = net.advance_dpb(fr[0], fr[1], dpb0, stage_idx=stage_idx, q_index=3)
+            r2 = net.encode_one_stage(fr[2], fr[3], False, r1["dpb"], output_path=os.path.join(td, "3.bin"), pic_width=W,
+                                      pic_height=H, skip_decoding=True, stage_idx=stage_idx, q_index=3)
+            a2 = net.advance_dpb(fr[2], fr[3], a1, stage_idx=stage_idx, q_index=3)
+            for k in ("mv_feature", "ref_mv_y"):
+                assert_same(a1[k], r1["dpb"][k], f"stage {stage_idx} first pair dpb.{k}")
+                assert_same(a2[k], r2["dpb"][k], f"stage {stage_idx} chained pair dpb.{k}")
+
+
+def _cross_decode(net):
+    """decode the five files the REAL reference wrote for one 128x128 pair (fixture `dec.file.*`) with the HIP decoder"""
+    from pMCTF.utils.stream_helper import decode_p
+    g = golden()
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with tempfile.TemporaryDirectory() as td:
+        for n in ("1.bin", "1_mv.bin", "1_C_main.bin", "0_main.bin", "0_C_main.bin"):
+            open(os.path.join(td, n), "wb").write(g[f"dec.file.{n}"].tobytes())
+        _, string = decode_p(os.path.join(td, "1_mv.bin"))
+        mv = net.decompress_mv(string, torch.float32, H, W, dpb, stage_idx=0, q_index=3)
+        luma = net.decompress_one_stage(os.path.join(td, "1.bin"), True, False, psize=128, q_index=3, stage_idx=0)
+        chroma = net.decompress_one_stage(os.path.join(td, "1_C_main.bin"), True, True, psize=128, q_index=3, stage_idx=0)
+    got = {"mv_hat": mv["mv_hat"], "mv_feature": mv["mv_feature"], "H_t": luma["H_t"]["x_hat"],
+           "L_t": luma["L_t"]["x_hat"], "H_tc": chroma["H_t"]["x_hat"], "L_tc": chroma["L_t"]["x_hat"]}
+    return {k: float(np.abs(v.cpu().numpy() - g[f"dec.{k}"]).max()) for k, v in got.items()}
+
+
+def test_cross_decode_reference_written_files(setup):
+    """Streams written by the REAL reference on the CPU (the `dec.file.*` arrays of the 128x128 fixture: one pair, H + L,
+    decoder-order LL) decoded by the HIP decoder.  A learned codec's decoder must compute every CDF row exactly as the
+    encoder did; across two float implementations (ATen vs PM-F32, last-bit differences of conv sums) that holds only
+    as long as no scale lands on a bin boundary.  Here: the motion stream, both H streams and the chroma L stream
+    decode in step with the reference's range coder and land on the reference decoder's tensors (fp noise only)."""
+    err = _cross_decode(setup[0])
+    for k in ("mv_hat", "mv_feature", "H_t", "H_tc", "L_tc"):
+        assert err[k] < 2e-3, (k, err[k])      # a desynchronised stream decodes to noise (hundreds of grey levels)
+
+
+@pytest.mark.xfail(strict=True, reason="measured: the reference-written luma L stream (0_main.bin, 5 985 bytes) desynchronises "
+                                       "in the HIP decoder (max error 509 grey levels): one CDF row differs between ATen "
+                                       "and PM-F32 arithmetic.  The oracle's PM-F32 back-end desynchronises at the same "
+                                       "place, its ATen back-end decodes it exactly (DESIGN.md §2).")
+def test_cross_decode_reference_written_luma_L_stream(setup):
+    assert _cross_decode(setup[0])["L_t"] < 2e-3
+
+
+def _pair_shard_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import pmctf_dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    net, _ = product_model(4)
+    fr = frames(W, H, 8, device="cuda", seed=11)
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_dist.encode_gop_pair_sharded(net, fr, H, W, 3, td, rank, world, dist)
+    torch.cuda.synchronize()
+    q.put((rank, enc["bits"], enc["bits_mv"],
+           [[t if t is None else t.cpu().numpy() for t in fc] for fc in enc["frames_coded"]], len(enc["results"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_sharding_two_ranks_real_codec(cuda):
+    """BASELINE configs[4] on what one box allows: two fresh processes share the GPU (gloo carries the relay and the
+    gather; on the 8-GPU node the same code runs over RCCL), GOP 8 at 128x128 with four ME stages and the REAL codec.
+    Both ranks must end with the subband tree, motion fields and bit counts of the single-process schedule, bit for
+    bit."""
+    import torch.multiprocessing as mp
+    import pmctf_gop
+    net, _ = product_model(4)
+    fr = frames(W, H, 8, device="cuda", seed=11)
+    with tempfile.TemporaryDirectory() as td:
+        ref = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pair_shard_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[4] for r in res) == [3, 4]             # 4+2+1 pairs: rank 0 codes 2+1+1, rank 1 codes 2+1
+    for rank, bits, bits_mv, fc, _ in res:
+        assert bits == ref["bits"] and bits_mv == ref["bits_mv"], rank
+        for a, b in zip(fc, ref["frames_coded"]):
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or np.array_equal(x, y.cpu().numpy()), rank
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_cross_gop_batched_equals_gop_by_gop(cuda, K):
+    """pmctf_gop.encode_gops_batched (stage s of K closed GOPs in one encode_stage_pairs call, motion context restarted
+    at every GOP boundary) against coding the GOPs one after the other with the pair-by-pair schedule: every file, bit
+    count and tensor of every GOP identical.  GOP 8, four ME stages, 128x128; the post-processing group size is lowered
+    so that the plane-group path is exercised too."""
+    import pmctf_gop
+    net, _ = product_model(4)
+    net.engine().post_process_max_px = 3 * 128 * 128
+    gops = [frames(W, H, 8, device="cuda", seed=100 + k) for k in range(K)]
+    refs, ref_files = [], []
+    for fr in gops:
+        with tempfile.TemporaryDirectory() as td:
+            refs.append(pmctf_gop.encode_gop(net, fr, H, W, 3, td))
+            ref_files.append({n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))})
+    tds = [tempfile.mkdtemp() for _ in range(K)]
+    outs = pmctf_gop.encode_gops_batched(net, gops, H, W, 3, tds)
+    for k in range(K):
+        files = {n: open(os.path.join(tds[k], n), "rb").read() for n in sorted(os.listdir(tds[k]))}
+        assert files == ref_files[k], f"GOP {k}: files differ"
+        assert outs[k]["bits"] == refs[k]["bits"] and outs[k]["bits_mv"] == refs[k]["bits_mv"], k
+        for a, b in zip(outs[k]["frames_coded"], refs[k]["frames_coded"]):
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or torch.equal(x, y), k
+
+
+@pytest.mark.parametrize("shape", [(1, 37, 53), (2, 8, 32), (1, 2, 5), (3, 19, 70), (1, 130, 33)])
+def test_fused_predict_update_equals_separate_launches(setup, shape):
+    """pu_fused.hip (the whole PredictUpdate CNN + the lifting arithmetic in one launch) against the chain of separate
+    launches it replaces, on plane sizes that do not divide into its 8x32 tiles, batches, and planes smaller than one
+    tile: the temporal predict / update filters and all four iWave lifting steps, forward and backward signs —
+    identical bits.  (Both paths are pinned to the oracle by test_mctf_bitexact / test_dwt_postprocess_bitexact.)"""
+    net, orc = setup
+    eng = net.engine()
+    n, h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    x = torch.from_numpy(rng.uniform(0, 255, (n, 1, h, w)).astype(np.float32)).cuda()
+    o = torch.from_numpy(rng.normal(0, 40, (n, 1, h, w)).astype(np.float32)).cuda()
+    wt = "hp_coder.wavelet_transform.lift_h"
+    got = {}
+    for fused in (True, False):
+        eng.pu_fused = fused
+        r = {"P": eng.predict_filter(0, x), "U": eng.update_filter(0, o)}
+        for cn, pn in (("conv_P1", "P_1"), ("conv_U1", "U_1"), ("conv_P2", "P_2"), ("conv_U2", "U_2")):
+            r[pn + "+"] = eng.lift_step(wt, cn, pn, x, o, 1.0)
+            r[pn + "-"] = eng.lift_step(wt, cn, pn, o, x, -1.0)
+        got[fused] = r
+    eng.pu_fused = True
+    for k in got[True]:
+        assert_same(got[True][k], got[False][k], f"{shape} {k}")
+    # and against the oracle directly
+    assert_same(got[True]["P"], orc.predict_filter(0, x.cpu()), "predict_filter vs oracle")
+    assert_same(got[True]["U"], orc.update_filter(0, o.cpu()), "update_filter vs oracle")
+    if h >= 2:
+        assert_same(got[True]["P_1+"], o.cpu() + orc.lift_branch(wt, "conv_P1", "P_1", x.cpu()), "lift step vs oracle")
+
+
+class _OracleCA:
+    """the oracle behind the model API the content-adaptive driver calls (encode_one_stage with or without a bitstream)"""
+
+    def __init__(self, orc):
+        self.orc = orc
+        self.num_me_stages = orc.num_me_stages
+
+    @staticmethod
+    def get_qp_num():
+        return 21
+
+    def inverse_MCTF(self, *a, **k):
+        return self.orc.inverse_MCTF(*a, **k)
+
+    def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
+                         psize=128, skip_decoding=True, stage_idx=0, q_index=0, me_downsample=1):
+        if output_path is None:
+            return self.orc.estimate_one_stage(ref_frame, cur_frame, code_lt, dpb, stage_idx, q_index, me_downsample)
+        return self.orc.encode_one_stage(ref_frame, cur_frame, code_lt, dpb, output_path=output_path,
+                                         pic_width=pic_width, pic_height=pic_height, psize=psize,
+                                         skip_decoding=skip_decoding, stage_idx=stage_idx, q_index=q_index,
+                                         me_downsample=me_downsample)
+
+
+@pytest.mark.parametrize("write_stream", [True, False])
+def test_content_adaptive_driver_matches_oracle(setup, write_stream):
+    """the GOP-size x motion-resolution RD search of test_pMCTF_CA.py:341-414 (pmctf_ca.search_gop) over
+    the HIP product and over the oracle: the same options tried in the same order, the same costs (write mode: bits are
+    file sizes, identical; estimate mode — encode_one_stage(output_path=None), the branch that is broken upstream —
+    within 1e-6 relative), the same choice.  8 frames of 128x128, GOP sizes {8, 4}, motion at full and half resolution."""
+    import pmctf_ca
+    net, orc = setup
+    fr = frames(W, H, 8, seed=31)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    with tempfile.TemporaryDirectory() as td, tempfile.TemporaryDirectory() as td2:
+        a = pmctf_ca.search_gop(net, frd, H, W, 3, td, write_stream=write_stream, ds_factors=(1, 2))
+        b = pmctf_ca.search_gop(_OracleCA(orc), fr, H, W, 3, td2, write_stream=write_stream, ds_factors=(1, 2))
+    assert [(s, d) for s, d, _ in a["trials"]] == [(s, d) for s, d, _ in b["trials"]]
+    assert (a["gop_choice"], a["ds_choice"], a["tested_opts"]) == (b["gop_choice"], b["ds_choice"], b["tested_opts"])
+    assert a["gop_choice"] in (8, 4) and a["ds_choice"] in (1, 2) and 2 <= a["tested_opts"] <= 3
+    for (_, _, ra), (_, _, rb) in zip(a["trials"], b["trials"]):
+        assert abs(ra - rb) <= 1e-6 * abs(rb)
+    if write_stream:
+        assert a["logs"]["bits"] == b["logs"]["bits"]
+        assert np.abs(np.array(a["logs"]["psnrs"]) - np.array(b["logs"]["psnrs"])).max() < 1e-9
+    else:
+        assert np.allclose(a["logs"]["bits"], b["logs"]["bits"], rtol=1e-6)
+    assert len(a["logs"]["bits"]) == 8 and a["logs"]["frame_types"].count(0) == 8 // a["gop_choice"]
+
+
+def test_estimate_only_branch_of_encode_one_stage(setup):
+    """encode_one_stage(output_path=None) (pMCTF_L.py:530-551): luma + chroma forward_one_stage, the dictionary of the
+    write branch with estimated bits; tensors bit-exact against the oracle's restatement, bits to 1e-6, and the motion
+    context usable by a following pair."""
+    net, orc = setup
+    fr = frames(W, H, 4, seed=23)
+    frd = [[y.cuda(), c.cuda()] for y, c in fr]
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    r = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=None, pic_width=W, pic_height=H, stage_idx=0, q_index=5)
+    o = orc.estimate_one_stage(fr[0], fr[1], True, dpb, 0, 5)
+    for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+        assert_same(r[k], o[k], k)
+    for k in ("bit_L", "bit_H", "bit_Lc", "bit_Hc", "bit_ME"):
+        assert abs(float(r[k]) - float(o[k])) <= 1e-6 * abs(float(o[k])), k
+    r2 = net.encode_one_stage(frd[2], frd[3], False, r["dpb"], output_path=None, pic_width=W, pic_height=H, q_index=5)
+    o2 = orc.estimate_one_stage(fr[2], fr[3], False, o["dpb"], 0, 5)
+    assert r2["bit_L"] is None and r2["bit_Lc"] is None
+    assert_same(r2["H_t"], o2["H_t"], "chained pair H_t")
+    assert abs(float(r2["bit_ME"]) - float(o2["bit_ME"])) <= 1e-6 * abs(float(o2["bit_ME"]))
