@@ -49,7 +49,9 @@ struct PuArgs {
     float c, sign, lw0, lw1, lw2, lb;
 };
 
-// one 16->16 3x3 layer on the matrix cores: src (row stride SW pixels, CP words per pixel) -> D fragments per segment
+// one 16->16 3x3 layer on the matrix cores: src (row stride SW pixels, CP words per pixel) -> D fragments per segment.
+// A wave walks its 16-pixel segments two at a time: two independent accumulator chains keep the matrix pipe issuing
+// back to back (a single chain waits 40 cycles per dependent v_mfma_f32_16x16x4_f32) and cover the LDS read latency.
 template <typename Epilogue>
 __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int npix, const float *wp, const float *bp,
                                            int wave, int lane, Epilogue epi) {
@@ -58,21 +60,41 @@ __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int
     for (int t = 0; t < 9; ++t) af[t] = *(const f32x4 *)(wp + t * 256 + lane * 4);
     const f32x4 bias = *(const f32x4 *)(bp + 4 * (lane >> 4));
     const int nseg = (npix + 15) >> 4;
-    for (int s = wave; s < nseg; s += 4) {
-        int idx = s * 16 + (lane & 15);
-        const bool live = idx < npix;
-        if (!live) idx = npix - 1;
-        const int r = idx / RW, c = idx - r * RW;
-        const float *b0 = src + (r * SW + c) * CP + (lane >> 4);
-        f32x4 acc = bias;
+    for (int s = wave; s < nseg; s += 8) {
+        const bool two = s + 4 < nseg;                      // wave-uniform
+        int idx0 = s * 16 + (lane & 15), idx1 = (s + 4) * 16 + (lane & 15);
+        const bool live0 = idx0 < npix, live1 = two && idx1 < npix;
+        if (!live0) idx0 = npix - 1;
+        if (!live1) idx1 = npix - 1;
+        const int r0 = idx0 / RW, c0 = idx0 - r0 * RW;
+        const int r1 = idx1 / RW, c1 = idx1 - r1 * RW;
+        const float *p0 = src + (r0 * SW + c0) * CP + (lane >> 4);
+        const float *p1 = src + (r1 * SW + c1) * CP + (lane >> 4);
+        f32x4 acc0 = bias, acc1 = bias;
+        if (two) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float *bb = b0 + ((t / 3) * SW + (t % 3)) * CP;
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * SW + (t % 3)) * CP;
+                float b0[4], b1[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], bb[ks * 4], acc, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) { b0[ks] = p0[toff + ks * 4]; b1[ks] = p1[toff + ks * 4]; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b0[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b1[ks], acc1, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * SW + (t % 3)) * CP;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], p0[toff + ks * 4], acc0, 0, 0, 0);
+            }
         }
-        if (live) epi(idx, r, c, acc);
+        if (live0) epi(idx0, r0, c0, acc0);
+        if (live1) epi(idx1, r1, c1, acc1);
     }
 }
 
@@ -113,32 +135,46 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
     }
     __syncthreads();
 
-    // ---- P1 (vector ALU): tanh(conv1) on the 14x38 region; thread = pixel, 16 couts in four groups of four
-    for (int idx = tid; idx < N1; idx += 256) {
-        const int r = idx / R1W, c = idx - r * R1W;
-        const int gy = y0 - 3 + r, gx = x0 - 3 + c;
-        float *dst = A1 + idx * CP;
-        if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) {
+    // ---- P1 (vector ALU): tanh(conv1) on the 14x38 region.  A thread owns up to three pixels; the 16 couts go in four
+    // groups of four so that a group's 36 weights + 4 biases are wave-uniform scalars while all pixels use them.
+    {
+        constexpr int PPT = (N1 + 255) / 256;
+        float iv[PPT][9];
+        bool ok[PPT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ((float2 *)dst)[q] = make_float2(0.0f, 0.0f);
-            continue;
+        for (int j = 0; j < PPT; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / R1W, c = idx - r * R1W;
+            const int gy = y0 - 3 + r, gx = x0 - 3 + c;
+            ok[j] = idx < N1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) iv[j][t] = idx < N1 ? in[(r + t / 3) * IW + c + t % 3] : 0.0f;
         }
-        float iv[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) iv[t] = in[(r + t / 3) * IW + c + t % 3];
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < 4; ++q) {
-            float v[4];
+            float wq[4][9], bq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int co = q * 4 + i;
-                float acc = a.b1[co];
+                bq[i] = a.b1[q * 4 + i];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[t], a.w1[co * 9 + t], acc);
-                v[i] = pm::tanhf_(acc);
+                for (int t = 0; t < 9; ++t) wq[i][t] = a.w1[(q * 4 + i) * 9 + t];
             }
-            ((float2 *)dst)[2 * q] = make_float2(v[0], v[1]);
-            ((float2 *)dst)[2 * q + 1] = make_float2(v[2], v[3]);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx >= N1) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float acc = bq[i];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[j][t], wq[i][t], acc);
+                    v[i] = ok[j] ? pm::tanhf_(acc) : 0.0f;
+                }
+                float2 *dst = (float2 *)(A1 + idx * CP + 4 * q);
+                dst[0] = make_float2(v[0], v[1]);
+                dst[1] = make_float2(v[2], v[3]);
+            }
         }
     }
     __syncthreads();
@@ -193,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         const int gy = y0 + r, gx = x0 + c;
         if (gy < a.H && gx < a.W) {
             float acc = a.b4[0];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {                       // one tap's 16 weights at a time stay scalar
                 const float2 *p = (const float2 *)(A3 + ((r + t / 3) * R3W + c + t % 3) * CP);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {

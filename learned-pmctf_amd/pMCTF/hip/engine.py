@@ -191,6 +191,7 @@ class HipEngine:
         self.multi_stream = os.environ.get("PMCTF_MULTI_STREAM", "0") == "1"   # luma/chroma on two streams
         self.multi_stream_max_pairs = int(os.environ.get("PMCTF_MULTI_STREAM_MAX_PAIRS", "2"))
         self.pu_fused = os.environ.get("PMCTF_PU_FUSED", "1") != "0"     # one launch per PredictUpdate + lifting step
+        self.pu_fused_max_px = int(os.environ.get("PMCTF_PU_FUSED_MAX_PX", "600000"))
         self.post_process_max_px = 8 * 1152 * 1920      # pixels per post-processing launch group (4.5 GB per 64-ch map)
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
@@ -237,20 +238,27 @@ class HipEngine:
         out = self.conv(p + ".conv4", 1, 1)(t)
         return out.view(N, 1, H, W)
 
+    def use_pu_fused(self, x):
+        """The one-launch PredictUpdate (pu_fused.hip) wins wherever the chain of eight launches is latency-bound
+        (tools/bench_pu.py: 23 vs 66-103 us on the level-2/3 planes, 79 vs 89-101 us at 288x960); on the largest planes
+        its halo re-computation (1.5x the matrix work, 3.8 tanh per output value) costs more than the HBM traffic it
+        saves, so those keep the separate launches.  Same bits either way."""
+        return self.pu_fused and x.numel() <= self.pu_fused_max_px
+
     def pu_convs(self, p):
         return tuple(self.conv(f"{p}.conv{k}", 1, 1) for k in (1, 2, 3, 4))
 
     def predict_filter(self, stage, x):
         """wavelet_transform_temporal_mctf.py:27-35: (x + 0.1*P(x)) * (1/sqrt2)"""
         p = f"temporal_filtering.{stage}.P_t"
-        if self.pu_fused:
+        if self.use_pu_fused(x):
             return ops.predict_update_fused(x, None, self.pu_convs(p), 0, c=1 / math.sqrt(2))
         pu = self.predict_update(p, x)
         return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 1 / math.sqrt(2))
 
     def update_filter(self, stage, x):
         p = f"temporal_filtering.{stage}.U_t"
-        if self.pu_fused:
+        if self.use_pu_fused(x):
             return ops.predict_update_fused(x, None, self.pu_convs(p), 0, c=0.5)
         pu = self.predict_update(p, x)
         return ew(EW_ADD_MULS_MULS, x, pu, 0.1, 0.5)
@@ -479,7 +487,7 @@ class HipEngine:
 
     def lift_step(self, wt, conv_name, pu_name, src, other, sign):
         """other + sign * branch(src): one lifting step (lifting_1d.py:105-118 forward, :150-163 backward)"""
-        if self.pu_fused and src.shape[2] >= 2:
+        if self.use_pu_fused(src) and src.shape[2] >= 2:
             w = self.sd[f"{wt}.{conv_name}.weight"].reshape(-1).tolist()
             b = float(self.sd[f"{wt}.{conv_name}.bias"].reshape(-1)[0])
             return ops.predict_update_fused(src, other, self.pu_convs(f"{wt}.{pu_name}"), 1, sign=sign,

@@ -16,6 +16,7 @@ estimated and coded at reduced resolution).
 """
 import os
 import os.path as osp
+import threading
 import time
 
 import torch
@@ -23,6 +24,7 @@ from torch import nn
 
 from pMCTF.entropy_models.entropy_models import BitEstimator
 from pMCTF.entropy_models.gaussian_model import CompressionModel
+from pMCTF.hip.deferred import Deferred, DeferredTensor, is_pending, unwrap
 from pMCTF.hip.engine import HipEngine
 from pMCTF.layers.modules import (DepthConvBlock, ME_Spynet, MvDec, MvEnc, TemporalLifting, get_hyper_dec_model,
                                   get_hyper_enc_model)
@@ -81,6 +83,11 @@ class pMCTF(nn.Module):
         self.two_stage_me = two_stage_me
         self.num_me_stages = num_me_stages
         self._engine = None
+        # encode_one_stage may defer: the pairs a harness hands over one by one are collected per temporal stage and
+        # coded as one batch when a result is first needed (pMCTF.hip.deferred).  PMCTF_LAZY=0 / lazy_stages=False: eager.
+        self.lazy_stages = os.environ.get("PMCTF_LAZY", "1") != "0"
+        self.lazy_max_pairs = int(os.environ.get("PMCTF_LAZY_MAX_PAIRS", "32"))
+        self._tls = threading.local()
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -116,15 +123,91 @@ class pMCTF(nn.Module):
         return self._engine
 
     # ------------------------------------------------------------------------------------------
+    # deferred pairs (one queue per calling thread)
+    def _queue(self):
+        q = getattr(self._tls, "q", None)
+        if q is None:
+            q = self._tls.q = {"key": None, "pairs": [], "dpb0": None}
+        return q
+
+    def flush(self, q=None):
+        """Code every pair collected so far (one encode_stage_pairs call) and resolve their deferred results; their
+        bitstream files exist from here on.  Called implicitly by every use of a deferred value and by every other
+        entry point of the model."""
+        q = self._queue() if q is None else q
+        recs, q["pairs"] = q["pairs"], []
+        if not recs:
+            return
+        key, dpb0, q["key"], q["dpb0"] = q["key"], q["dpb0"], None, None
+        code_lt, stage_idx, q_index, psize, pic_width, pic_height = key[:6]
+        try:
+            results, _ = self.encode_stage_pairs([r["pair"] for r in recs], code_lt, dpb0, [r["path"] for r in recs],
+                                                 pic_width, pic_height, psize=psize, stage_idx=stage_idx, q_index=q_index,
+                                                 chain_reset=[i for i, r in enumerate(recs) if r["reset"] and i > 0])
+        except BaseException as e:
+            for r in recs:
+                r["error"] = e
+            raise
+        for r, res in zip(recs, results):
+            r["result"] = res
+
+    def _defer(self, ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx, q_index):
+        q = self._queue()
+        # inputs produced by pairs that are still pending (a later temporal stage): they are needed now
+        if any(is_pending(t) for t in (*ref_frame, *cur_frame)):
+            self.flush()
+        ref_frame, cur_frame = unwrap(list(ref_frame)), unwrap(list(cur_frame))
+        key = (code_lt, stage_idx, q_index, psize, pic_width, pic_height, tuple(ref_frame[0].shape),
+               tuple(ref_frame[1].shape), ref_frame[0].device)
+        mvf, rmy = dpb["mv_feature"], dpb["ref_mv_y"]
+        last = q["pairs"][-1] if q["pairs"] else None
+        chained = last is not None and mvf is last["out"]["dpb"]["mv_feature"] and rmy is last["out"]["dpb"]["ref_mv_y"]
+        fresh = mvf is None and rmy is None
+        if q["pairs"] and (key != q["key"] or not (chained or fresh) or len(q["pairs"]) >= self.lazy_max_pairs):
+            self.flush()
+            chained = False
+        if not q["pairs"]:
+            q["key"] = key
+            q["dpb0"] = {"mv_feature": unwrap(mvf), "ref_mv_y": unwrap(rmy)}
+        rec = {"pair": (ref_frame, cur_frame), "path": output_path, "reset": fresh and not chained, "result": None,
+               "error": None}
+
+        def get(k, sub=None):
+            def thunk():
+                if rec["result"] is None:
+                    if rec["error"] is not None:
+                        raise RuntimeError("the deferred encode of this pair failed") from rec["error"]
+                    self.flush(q)
+                v = rec["result"][k]
+                return v[sub] if sub is not None else v
+            return thunk
+        ready = lambda: rec["result"] is not None
+        out = {k: DeferredTensor(get(k), ready) for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat")}
+        for k in ("bit_H", "bit_Hc", "bit_ME", "encoding_time"):
+            out[k] = Deferred(get(k), ready)
+        out["bit_L"] = Deferred(get("bit_L"), ready) if code_lt else None
+        out["bit_Lc"] = Deferred(get("bit_Lc"), ready) if code_lt else None
+        out["dpb"] = {"mv_feature": DeferredTensor(get("dpb", "mv_feature"), ready),
+                      "ref_mv_y": DeferredTensor(get("dpb", "ref_mv_y"), ready)}
+        out["decoding_time"] = 0
+        if self.engine().keep_streams:
+            out["files"], out["traces"] = Deferred(get("files"), ready), Deferred(get("traces"), ready)
+        rec["out"] = out
+        q["pairs"].append(rec)
+        return out
+
+    # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def inverse_MCTF(self, L_t, H_t, mv_hat, downscale=False, stage_idx=0):
         """pMCTF_L.py:314-330"""
+        L_t, H_t, mv_hat = unwrap((L_t, H_t, mv_hat))
         c = lambda t: t.contiguous()
         return self.engine().inverse_MCTF(c(L_t), c(H_t), c(mv_hat), downscale=downscale, stage_idx=stage_idx)
 
     @torch.no_grad()
     def forward_MCTF(self, ref_frame, cur_frame, mv_hat, stage_idx=0):
         """pMCTF_L.py:297-312"""
+        ref_frame, cur_frame, mv_hat = unwrap((ref_frame, cur_frame, mv_hat))
         c = lambda t: t.contiguous()
         return self.engine().forward_MCTF(c(ref_frame), c(cur_frame), c(mv_hat), stage_idx)
 
@@ -137,6 +220,7 @@ class pMCTF(nn.Module):
     def decompress_mv(self, string, dtype, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """pMCTF_L.py:497-523 — returns mv_hat (1,2,H,W) and the MV decoder contexts (logical NCHW views)"""
         self._check_ds(me_downsample)
+        dpb = unwrap(dpb)
         d = self.engine().decompress_mv(string, height, width, dpb, stage_idx=stage_idx, q_index=q_index,
                                         me_downsample=me_downsample)
         return {"mv_hat": d["mv_hat"], "mv_feature": d["mv_feature"].permute(0, 3, 1, 2),
@@ -150,6 +234,7 @@ class pMCTF(nn.Module):
     def _decompress_files(self, files, code_lt, psize, q_index, stage_idx):
         """H (and L) files of the given (file_name, ischroma) entries; their sequential LL parts decode concurrently"""
         from pMCTF.hip.engine import get_curr_q
+        self.flush()            # the files of deferred pairs must exist before they are read
         eng = self.engine()
         qp_scale = get_curr_q(eng.sd[f"hp_q_scale.{stage_idx}"], q_index) if self.quant_stage else None
         jobs = []
@@ -185,6 +270,7 @@ class pMCTF(nn.Module):
         further closed GOP when the same stage of several GOPs is coded in one call (pmctf_gop.encode_gops_batched)."""
         eng = self.engine()
         dev = next(self.parameters()).device
+        pairs, dpb = unwrap(list(pairs)), unwrap(dpb)
         c = lambda t: t.to(dev).contiguous()
         start = time.time()
         keep = eng.keep_streams
@@ -283,6 +369,7 @@ class pMCTF(nn.Module):
         needs.  Used by pair-level sharding (pmctf_dist.encode_gop_pair_sharded): the context chain of the motion codec
         is the only dependency between the pairs of a stage, and a rank re-computes it rather than waiting for it."""
         self._check_ds(me_downsample)
+        ref_frame, cur_frame, dpb = unwrap((list(ref_frame), list(cur_frame), dpb))
         eng = self.engine()
         dev = next(self.parameters()).device
         c = lambda t: t.to(dev).contiguous()
@@ -298,6 +385,7 @@ class pMCTF(nn.Module):
         self._check_ds(me_downsample)
         if self.training:
             raise NotImplementedError("training forward (noise quantisation, gradients) is not part of this build")
+        ref_frame, cur_frame, dpb, mv_hat = unwrap((ref_frame, cur_frame, dpb, mv_hat))
         eng = self.engine()
         dev = next(self.parameters()).device
         ref, cur = ref_frame.to(dev).contiguous(), cur_frame.to(dev).contiguous()
@@ -340,6 +428,14 @@ class pMCTF(nn.Module):
         delivers the context once the motion has been estimated, and `on_dpb(dpb)` is called with the NEXT pair's
         context as soon as the motion codec has produced it, before the subbands are coded."""
         self._check_ds(me_downsample)
+        if (self.lazy_stages and output_path is not None and skip_decoding and me_downsample == 1 and on_dpb is None
+                and not callable(dpb)):
+            return self._defer(ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx,
+                               q_index)
+        self.flush()
+        ref_frame, cur_frame = unwrap((list(ref_frame), list(cur_frame)))
+        if not callable(dpb):
+            dpb = unwrap(dpb)
         if output_path is None:
             # Estimate-only branch (pMCTF_L.py:530-551): the same networks with Laplace / factorized bit estimates, no
             # range coding.  The reference builds `dpb` from result["mv_feature"] / result["ref_mv_y"], keys that

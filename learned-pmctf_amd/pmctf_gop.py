@@ -142,14 +142,19 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
             frames_coded[i_ref] = [r["L_t"], r["L_tc"], None]
             frames_coded[i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
             dpb = r["dpb"]
-            bits[i_cur] = float(r["bit_H"] + r["bit_ME"])
-            bits_mv[i_cur] = float(r["bit_ME"])
+            # as the harness does (test_pMCTF_flex.py:236-258): the numbers are only stored here, not looked at — a codec
+            # that defers its results (the MI355X build batches the pairs of a stage) keeps deferring
+            bits[i_cur] = r["bit_H"] + r["bit_ME"]
+            bits_mv[i_cur] = r["bit_ME"]
             if code_lt:
-                bits[i_ref] = float(r["bit_L"])
+                bits[i_ref] = r["bit_L"]
                 bits_mv[i_ref] = 0.0
             results.append(r)
             if on_pair is not None:
                 on_pair(stage_idx, i_ref, i_cur, r)
+    bits = [None if b is None else float(b) for b in bits]             # the harness's log step (generate_log_json)
+    bits_mv = [None if b is None else float(b) for b in bits_mv]
+    frames_coded = [[t if t is None or isinstance(t, torch.Tensor) else t.force() for t in fc] for fc in frames_coded]
     return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
 
 

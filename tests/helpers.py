@@ -12,8 +12,10 @@ def golden(name="reference_128x128.npz"):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def product_model(num_me_stages=1, device="cuda"):
-    """pMCTF (HIP product) with the deterministic synthetic weights, ready to encode."""
+def product_model(num_me_stages=1, device="cuda", lazy=False):
+    """pMCTF (HIP product) with the deterministic synthetic weights, ready to encode.  lazy=False: encode_one_stage
+    returns finished results call by call (what most tests assume: they look at files and tensors right away);
+    lazy=True: the product's default, pairs deferred and coded per temporal stage (pMCTF.hip.deferred)."""
     import pmctf_synth
     from pMCTF.models.video.pMCTF_L import pMCTF
     net = pMCTF(num_me_stages=num_me_stages).eval()
@@ -21,6 +23,7 @@ def product_model(num_me_stages=1, device="cuda"):
     net.load_state_dict(sd, strict=True)
     net = net.to(device)
     net.update(force=True)
+    net.lazy_stages = lazy
     return net, sd
 
 
@@ -39,6 +42,7 @@ def frames(width, height, n, device="cpu", seed=1234):
 
 
 def assert_same(a, b, what):
+    a, b = (x.force() if hasattr(x, "force") else x for x in (a, b))        # deferred results of the product
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)

@@ -853,6 +853,7 @@ def test_fused_predict_update_equals_separate_launches(setup, shape):
     o = torch.from_numpy(rng.normal(0, 40, (n, 1, h, w)).astype(np.float32)).cuda()
     wt = "hp_coder.wavelet_transform.lift_h"
     got = {}
+    eng.pu_fused_max_px = 1 << 40
     for fused in (True, False):
         eng.pu_fused = fused
         r = {"P": eng.predict_filter(0, x), "U": eng.update_filter(0, o)}
@@ -860,7 +861,7 @@ def test_fused_predict_update_equals_separate_launches(setup, shape):
             r[pn + "+"] = eng.lift_step(wt, cn, pn, x, o, 1.0)
             r[pn + "-"] = eng.lift_step(wt, cn, pn, o, x, -1.0)
         got[fused] = r
-    eng.pu_fused = True
+    eng.pu_fused, eng.pu_fused_max_px = True, 600000
     for k in got[True]:
         assert_same(got[True][k], got[False][k], f"{shape} {k}")
     # and against the oracle directly
@@ -914,7 +915,9 @@ def test_content_adaptive_driver_matches_oracle(setup, write_stream):
         assert abs(ra - rb) <= 1e-6 * abs(rb)
     if write_stream:
         assert a["logs"]["bits"] == b["logs"]["bits"]
-        assert np.abs(np.array(a["logs"]["psnrs"]) - np.array(b["logs"]["psnrs"])).max() < 1e-9
+        # reconstructions are bit-identical; the harness-side PSNR is a torch mean evaluated on the device the frames
+        # live on, and the GPU / CPU reductions sum in different orders (1e-6 dB)
+        assert np.abs(np.array(a["logs"]["psnrs"]) - np.array(b["logs"]["psnrs"])).max() < 1e-5
     else:
         assert np.allclose(a["logs"]["bits"], b["logs"]["bits"], rtol=1e-6)
     assert len(a["logs"]["bits"]) == 8 and a["logs"]["frame_types"].count(0) == 8 // a["gop_choice"]
@@ -939,3 +942,49 @@ def test_estimate_only_branch_of_encode_one_stage(setup):
     assert r2["bit_L"] is None and r2["bit_Lc"] is None
     assert_same(r2["H_t"], o2["H_t"], "chained pair H_t")
     assert abs(float(r2["bit_ME"]) - float(o2["bit_ME"])) <= 1e-6 * abs(float(o2["bit_ME"]))
+
+
+def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
+    """The product's default mode: encode_one_stage hands back deferred results, the pairs a harness passes one by one
+    are collected per temporal stage and coded as ONE batch when a value is first needed (pMCTF.hip.deferred).  The
+    harness loop of test_pMCTF_flex.py (pmctf_gop.encode_gop) must give exactly the eager results — files, bit counts,
+    subband tree, reconstruction — with one encode_stage_pairs call per stage; and looking at a result early simply
+    codes what has been collected so far."""
+    import pmctf_gop
+    net, _ = product_model(4, lazy=False)
+    fr = frames(W, H, 8, device="cuda", seed=41)
+    with tempfile.TemporaryDirectory() as td:
+        ref = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+        ref_files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+        ref_rec = pmctf_gop.decode_gop(net, [list(f) for f in ref["frames_coded"]])
+    net.lazy_stages = True
+    calls = []
+    orig = net.encode_stage_pairs
+    net.encode_stage_pairs = lambda pairs, *a, **k: (calls.append(len(pairs)), orig(pairs, *a, **k))[1]
+    with tempfile.TemporaryDirectory() as td:
+        lazy = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+        assert calls == [4, 2, 1], calls                     # one batch per temporal stage
+        files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+        rec = pmctf_gop.decode_gop(net, [list(f) for f in lazy["frames_coded"]])
+    assert files == ref_files and lazy["bits"] == ref["bits"] and lazy["bits_mv"] == ref["bits_mv"]
+    for a, b in zip(lazy["frames_coded"], ref["frames_coded"]):
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+    for a, b in zip(rec, ref_rec):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # a caller that looks at every result right away gets the pair-by-pair schedule, and its files exist at that moment
+    del calls[:]
+    dpb = {"mv_feature": None, "ref_mv_y": None}
+    with tempfile.TemporaryDirectory() as td:
+        r1 = net.encode_one_stage(fr[0], fr[1], False, dpb, output_path=os.path.join(td, "1.bin"), pic_width=W,
+                                  pic_height=H, skip_decoding=True, stage_idx=0, q_index=3)
+        assert os.listdir(td) == [] and calls == []          # nothing has been needed yet
+        bits = r1["bit_H"] + r1["bit_ME"]                     # arithmetic keeps deferring (test_pMCTF_flex.py:236)
+        assert calls == []
+        r2 = net.encode_one_stage(fr[2], fr[3], False, r1["dpb"], output_path=os.path.join(td, "3.bin"), pic_width=W,
+                                  pic_height=H, skip_decoding=True, stage_idx=0, q_index=3)
+        assert float(bits) == ref["bits"][1] and calls == [2]           # first use: both collected pairs are coded
+        assert sorted(os.listdir(td)) == ["1.bin", "1_C_main.bin", "1_mv.bin", "3.bin", "3_C_main.bin", "3_mv.bin"]
+        assert float(r2["bit_H"] + r2["bit_ME"]) == ref["bits"][3]
+        assert torch.equal(torch.round(r2["H_t"]), torch.round(ref["frames_coded"][3][0]))     # torch functions force
+    net.encode_stage_pairs = orig
