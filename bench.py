@@ -122,6 +122,8 @@ def main():
                     help="what `value` times.  pairs (default): the reference harness's schedule, one encode_one_stage "
                          "call per frame pair.  stages: the pairs of each temporal stage as one batch "
                          "(encode_stage_pairs): same files and bits, larger launches.")
+    ap.add_argument("--aux_precisions", default="bf16x3,bf16x2,bf16",
+                    help="auxiliary reduced-precision profiles measured after the exact run ('' to skip)")
     ap.add_argument("--cross_gops", type=int, default=4, help="K of the auxiliary cross-GOP stage-batched figure")
     ap.add_argument("--inflight", type=int, default=1,
                     help="closed GOPs coded concurrently on this GPU (one host thread + HIP stream each; a step is then "
@@ -342,6 +344,40 @@ def main():
                         "roofline": roofline_of(ev_x, kname["stages"] + ", f32 MFMA 16x16x4", traffic)}
                     del gops
                     last.pop("encs", None)
+        if world == 1 and args.inflight == 1 and not args.no_aux and args.aux_precisions:
+            # AUXILIARY arithmetic profiles (second conv variant): the dense 3x3 convolutions on bf16 MFMA
+            # with operands split into 3 / 2 / 1 planes.  Reported beside the exact figure, never instead of it, with what
+            # they cost in fidelity against the real reference's digests; dtype of the headline stays f32.
+            import numpy as np
+            out["aux_profiles"] = {}
+            ref_bits = ref_psnr = None
+            if os.path.exists(fix):
+                g = np.load(fix)
+                ref_bits, ref_psnr = g["gop.bits"], g["gop.psnr_yuv"]
+            for prec in args.aux_precisions.split(","):
+                net.precision = prec
+                with torch.no_grad():
+                    t_p, ev_p = timed(step_main, max(1, min(args.steps, 3)), 1)
+                    k_p = max(1, min(args.steps, 3))
+                    e_p = last["enc"]
+                    ps_p = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, e_p["frames_coded"]), frames, H, W)
+                blk = {"value": args.gop * k_p / t_p, "unit": "frames/s", "ms_per_step": t_p / k_p * 1e3, "steps": k_p,
+                       "dtype": {"bf16x3": "bf16 x3 split operands, f32 accumulate", "bf16x2": "bf16 x2 split, f32 accumulate",
+                                 "bf16": "bf16, f32 accumulate"}.get(prec, prec),
+                       "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px (conv_split.hip); all else exact f32",
+                       "bpp": sum(e_p["bits"]) / (args.gop * W * H), "psnr_yuv": sum(p["yuv"] for p in ps_p) / len(ps_p),
+                       "rel_bits_vs_exact_profile": (sum(e_p["bits"]) - sum(enc["bits"])) / sum(enc["bits"]),
+                       "max_abs_dpsnr_vs_exact_profile_db": max(abs(p["yuv"] - q["yuv"]) for p, q in zip(ps_p, ps)),
+                       "dominant_conv_tflops_equivalent": roofline_of(ev_p, "", None)["achieved"]}
+                if ref_bits is not None:
+                    db = np.array(e_p["bits"]) - ref_bits
+                    blk["vs_reference_cpu"] = {"frames_with_identical_bits": int((db == 0).sum()), "frames": int(db.size),
+                                               "max_abs_bit_delta_per_frame": float(np.abs(db).max()),
+                                               "rel_total_bits": float(db.sum() / ref_bits.sum()),
+                                               "max_abs_dpsnr_db": float(np.abs(np.array([p["yuv"] for p in ps_p]) - ref_psnr).max())}
+                out["aux_profiles"][prec] = blk
+            net.precision = "f32"
+            net.engine()
         out["host"] = dict(net.engine().stats)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, args.gop, args.q_index)

@@ -153,6 +153,19 @@ int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *a, const in
  * (3 identical channels, pMCTF_L.py:453-454): planes im1[HW], warped[HW], flow_up[2][HW] -> NHWC [HW,8]. */
 int pmctf_spynet_pack8_f32(const float *im1, const float *warped, const float *flow_up, float *out, int H, int W,
                            void *stream);
+/* AUXILIARY reduced-precision profile of the dense 3x3 'same' stride-1 convolutions (conv_split.hip; SURVEY.md §7 step 5,
+ * second variant): bf16-input / f32-accumulate MFMA with both operands split into nsplit bf16 planes (3: ~2^-22 relative
+ * per product, 2: ~2^-16, 1: plain bf16).  Same interface and epilogue as pmctf_conv2d_nhwc_f32 (same reference call sites:
+ * context_fusion_4step.py:12-20, postprocessing.py:9-18,35-44, context_fusion.py:56-128); NOT bit-exact against the
+ * oracle — selected only by HipEngine(precision=...), never by the parity path.  Cin % 16 == 0, Cout in {64, 112}. */
+int pmctf_conv3x3_split_supported(int Cin, int Cout);
+int64_t pmctf_conv3x3_split_packed_size(int Cout, int Cin, int nsplit);          /* uint16 elements */
+int pmctf_conv3x3_split_pack_weights(const float *w_oihw, const float *bias, int Cout, int Cin, int nsplit,
+                                     uint16_t *w_packed, float *bias_packed);     /* HOST pointers */
+int pmctf_conv3x3_split_f32(const float *x, const uint16_t *w_packed, const float *bias_packed, const float *res1,
+                            const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int nsplit, int act,
+                            float slope, void *stream);
+
 /* The whole PredictUpdate CNN of a lifting step as ONE launch (pu_fused.hip): 1->16, 16->16 tanh, 16->16 (+c1), 16->1,
  * 3x3 zero-padded, with the arithmetic around it.  x / other / out: single-channel planes (N,1,H,W).
  *   mode 0 — temporal predict / update filter, pMCTF/layers/wavelet_transform_temporal_mctf.py:27-45:

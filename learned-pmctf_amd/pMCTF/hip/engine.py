@@ -157,8 +157,19 @@ class RangeCoderPool:
 
 
 class HipEngine:
+    PRECISIONS = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
+
     def __init__(self, state_dict, num_me_stages, device, gaussian_tables, bit_est_tables, decomp_levels=4,
-                 coder_threads=4):
+                 coder_threads=4, precision="f32"):
+        """precision: "f32" = PM-F32, the product's arithmetic (bit-exact against the oracle).  "bf16x3" / "bf16x2" /
+        "bf16": the AUXILIARY reduced-precision profile — the dense 3x3 convolutions with 64 / 112 couts on planes of at
+        least ops.SPLIT_MIN_PX pixels run on bf16 MFMA with operands split into 3 / 2 / 1 planes (conv_split.hip); every
+        other kernel is unchanged.  Encoder and decoder built with the same profile agree bit for bit; results differ
+        from PM-F32 in the last bits, so no parity claim is made for it."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self.precision = precision
+        self.nsplit = self.PRECISIONS[precision]
         if not torch.cuda.is_available():
             raise RuntimeError("pMCTF HIP engine needs a GPU: the product path has no CPU fallback")
         _lib.hip()
@@ -201,7 +212,8 @@ class HipEngine:
         key = (p, stride, padding)
         c = self._convs.get(key)
         if c is None:
-            c = ops.Conv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride, (padding, padding), self.dev)
+            c = ops.Conv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride, (padding, padding), self.dev,
+                           split=self.nsplit)
             torch.cuda.synchronize(self.dev)      # packed weights are used from several streams later
             self._convs[key] = c
         return c

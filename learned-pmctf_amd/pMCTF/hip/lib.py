@@ -41,6 +41,10 @@ _SIGS = {
     "pmctf_bilinear_down_f32": (ci, [vp, vp, ci, ci, ci, ci, cf, vp]),
     "pmctf_ew_f32": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp]),
     "pmctf_spynet_pack8_f32": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+    "pmctf_conv3x3_split_supported": (ci, [ci, ci]),
+    "pmctf_conv3x3_split_packed_size": (i64, [ci, ci, ci]),
+    "pmctf_conv3x3_split_pack_weights": (ci, [vp, vp, ci, ci, ci, vp, vp]),
+    "pmctf_conv3x3_split_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
     "pmctf_predict_update_fused_f32": (ci, [vp] * 11 + [ci] * 4 + [cf] * 6 + [vp]),
     "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, vp]),
     "pmctf_nearest_up2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, vp]),

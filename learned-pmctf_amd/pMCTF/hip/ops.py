@@ -17,6 +17,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 # Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
 # dominant kernel).  CONV_PROBE = {"match": fn(conv, x, stride) -> bool, "events": [(start, end, flops)]}
 CONV_PROBE = None
+SPLIT_MIN_PX = 30000       # planes below this keep the exact f32 kernels under the reduced-precision profile (too few tiles)
 
 
 def _stream():
@@ -40,7 +41,9 @@ class Conv2d:
     """A packed nn.Conv2d (groups=1): weights re-laid out once for the MFMA kernel
     (Cin % 4 == 0) or kept OIHW for the small-Cin vector kernel."""
 
-    def __init__(self, weight, bias, stride=1, padding=(0, 0), device="cuda"):
+    def __init__(self, weight, bias, stride=1, padding=(0, 0), device="cuda", split=0):
+        """split = 1, 2 or 3: ALSO pack bf16-split weights for the auxiliary reduced-precision kernel (conv_split.hip) and
+        use it on planes of at least SPLIT_MIN_PX output pixels when the shape is supported; 0 (default): exact f32 only."""
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
@@ -68,6 +71,19 @@ class Conv2d:
                                                    wp.ctypes.data, bp.ctypes.data), "pack_weights")
             self.w = torch.from_numpy(wp).to(device)
             self.b = torch.from_numpy(bp).to(device)
+        self.split = 0
+        if (split and not self.small and not self.few and self.stride == 1 and self.KH == 3 and self.KW == 3
+                and self.pad == (1, 1) and L.pmctf_conv3x3_split_supported(self.Cin, self.Cout)):
+            n16 = L.pmctf_conv3x3_split_packed_size(self.Cout, self.Cin, int(split))
+            wp16 = np.empty(n16, np.uint16)
+            bp2 = np.empty(L.pmctf_conv2d_packed_bias_size(self.Cout), np.float32)
+            wn = w.numpy()
+            bn = None if b is None else b.numpy()
+            _lib.check(L.pmctf_conv3x3_split_pack_weights(wn.ctypes.data, None if bn is None else bn.ctypes.data,
+                                                          self.Cout, self.Cin, int(split), wp16.ctypes.data,
+                                                          bp2.ctypes.data), "split pack_weights")
+            self.w16 = torch.from_numpy(wp16.view(np.int16)).to(device)
+            self.split = int(split)
 
     def out_shape(self, x):
         N, H, W, Cin = x.shape
@@ -95,9 +111,14 @@ class Conv2d:
         if probe is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(fn(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin, self.Cout,
-                      self.KH, self.KW, self.stride, self.pad[0], self.pad[1], int(act), float(slope), _stream()),
-                   "conv2d")
+        if self.split and N * H * W >= SPLIT_MIN_PX:        # auxiliary reduced-precision profile (never the parity path)
+            _lib.check(L.pmctf_conv3x3_split_f32(_p(x), C.c_void_p(self.w16.data_ptr()), _p(self.b), _p(res1), _p(res2),
+                                                 _p(y), N, H, W, Cin, self.Cout, self.split, int(act), float(slope),
+                                                 _stream()), "conv3x3_split")
+        else:
+            _lib.check(fn(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin, self.Cout,
+                          self.KH, self.KW, self.stride, self.pad[0], self.pad[1], int(act), float(slope), _stream()),
+                       "conv2d")
         if probe is not None:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))

@@ -85,6 +85,9 @@ class pMCTF(nn.Module):
         self._engine = None
         # encode_one_stage may defer: the pairs a harness hands over one by one are collected per temporal stage and
         # coded as one batch when a result is first needed (pMCTF.hip.deferred).  PMCTF_LAZY=0 / lazy_stages=False: eager.
+        # arithmetic profile of the engine: "f32" (PM-F32, the parity path) or the auxiliary reduced-precision profiles
+        # "bf16x3" / "bf16x2" / "bf16" (HipEngine docstring); set before the first encode, or call update(force=True)
+        self.precision = os.environ.get("PMCTF_PRECISION", "f32")
         self.lazy_stages = os.environ.get("PMCTF_LAZY", "1") != "0"
         self.lazy_max_pairs = int(os.environ.get("PMCTF_LAZY_MAX_PAIRS", "32"))
         self._tls = threading.local()
@@ -109,6 +112,8 @@ class pMCTF(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def engine(self):
+        if self._engine is not None and self._engine.precision != self.precision:
+            self._engine = None
         if self._engine is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
@@ -119,7 +124,7 @@ class pMCTF(nn.Module):
                 raise RuntimeError("call update(force=True) before encoding")
             g = {"cdf_info": ge.get_cdf_info(), "log_scale_min": ge.log_scale_min, "log_scale_step": ge.log_scale_step}
             z = [self.mv_bit_est[i].get_cdf_info() for i in range(self.num_me_stages)]
-            self._engine = HipEngine(self.state_dict(), self.num_me_stages, dev, g, z)
+            self._engine = HipEngine(self.state_dict(), self.num_me_stages, dev, g, z, precision=self.precision)
         return self._engine
 
     # ------------------------------------------------------------------------------------------

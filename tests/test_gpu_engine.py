@@ -988,3 +988,46 @@ def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
         assert float(r2["bit_H"] + r2["bit_ME"]) == ref["bits"][3]
         assert torch.equal(torch.round(r2["H_t"]), torch.round(ref["frames_coded"][3][0]))     # torch functions force
     net.encode_stage_pairs = orig
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_reduced_precision_profile_is_self_consistent(cuda, precision):
+    """The AUXILIARY arithmetic profiles (HipEngine(precision=...): the dense 3x3 convolutions on bf16 MFMA with split
+    operands) earn no parity claim, but they must be usable: deterministic, decodable by the same build bit for bit
+    (decoder in the loop == encoder's reconstruction), close to the exact profile (bits within 1 % / 10 %, PSNR within
+    0.01 / 1 dB), and the exact profile must be untouched by their existence."""
+    import pmctf_gop
+    from pMCTF.hip import ops
+    w, h = 448, 256
+    fr = frames(w, h, 4, device="cuda", seed=77)
+    exact_net, _ = product_model(1)
+    with tempfile.TemporaryDirectory() as td:
+        exact = pmctf_gop.encode_gop(exact_net, fr, h, w, 3, td)
+        exact_ps = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(exact_net, [list(f) for f in exact["frames_coded"]]), fr, h, w)
+    net, _ = product_model(1)
+    net.precision = precision
+    old = ops.SPLIT_MIN_PX
+    ops.SPLIT_MIN_PX = 4096          # small test planes: let the level-0/1 subbands take the split kernel
+    try:
+        assert net.engine().precision == precision and net.engine().nsplit == {"bf16x3": 3, "bf16": 1}[precision]
+        with tempfile.TemporaryDirectory() as td:
+            a = pmctf_gop.encode_gop(net, fr, h, w, 3, td)
+            files_a = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+            b = pmctf_gop.encode_gop(net, fr, h, w, 3, td)
+            files_b = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+            assert files_a == files_b, "reduced-precision encode is not deterministic"
+            ps = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, [list(f) for f in a["frames_coded"]]), fr, h, w)
+            # the real decoder of the same build reproduces the encoder's reconstruction from the files
+            dpb = {"mv_feature": None, "ref_mv_y": None}
+            e = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=w,
+                                     pic_height=h, skip_decoding=True, stage_idx=0, q_index=3)
+            d = net.encode_one_stage(fr[0], fr[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=w,
+                                     pic_height=h, skip_decoding=False, stage_idx=0, q_index=3)
+            for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+                assert_same(d[k], e[k], f"{precision}: decoded {k} vs encoder reconstruction")
+    finally:
+        ops.SPLIT_MIN_PX = old
+    rel_bits = abs(sum(a["bits"]) - sum(exact["bits"])) / sum(exact["bits"])
+    dpsnr = max(abs(p["yuv"] - q["yuv"]) for p, q in zip(ps, exact_ps))
+    print(f"{precision}: total bits {sum(a['bits']):.0f} vs exact {sum(exact['bits']):.0f} ({rel_bits:.2e}), max |dPSNR| {dpsnr:.2e} dB")
+    assert rel_bits < (0.01 if precision == "bf16x3" else 0.10) and dpsnr < (0.01 if precision == "bf16x3" else 1.0)

