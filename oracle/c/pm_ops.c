@@ -83,7 +83,7 @@ static void pm_conv_job(long job, void *vctx) {
     const float b = c->bias ? c->bias[co] : 0.0f;
     for (int xb = 0; xb < Wo; xb += PM_XB) {
         float acc[PM_XB];
-        if (stride == 1 && pm_conv_order == 1) {
+        if (stride == 1 && pm_conv_order == 1 && KH * KW > 1) {
             /* EXPERIMENT: oneDNN jit:avx512_core order — per 16-channel block a chain from zero, block sums added to
              * the running output, bias added after the first block */
             __m256 t0 = _mm256_setzero_ps(), t1 = t0, t2 = t0, t3 = t0;
@@ -109,7 +109,7 @@ static void pm_conv_job(long job, void *vctx) {
             }
             _mm256_storeu_ps(acc, t0); _mm256_storeu_ps(acc + 8, t1);
             _mm256_storeu_ps(acc + 16, t2); _mm256_storeu_ps(acc + 24, t3);
-        } else if (pm_conv_order == 1) {
+        } else if (pm_conv_order == 1 && KH * KW > 1) {
             float tot[PM_XB];
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
                 const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;

@@ -383,6 +383,8 @@ def test_corrupt_streams_fail_cleanly(setup):
             "garbled payload": good[:24] + rng.integers(0, 256, len(good) - 24, dtype=np.uint8).tobytes(),
             "length field too long": good[:12] + struct.pack(">I", len(good) * 2) + good[16:],
         }
+        ref = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
+        outcomes = {}
         for name, data in cases.items():
             if name == "truncated":      # keep the header's length field consistent with what is there
                 data = data[:12] + struct.pack(">I", len(data) - 16) + data[16:]
@@ -391,11 +393,16 @@ def test_corrupt_streams_fail_cleanly(setup):
                 out = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
                 torch.cuda.synchronize()
                 assert out.shape == (1, 1, 128, 128), name
-            except (ValueError, RuntimeError):
-                pass
-        open(fn, "wb").write(good)       # and the coder still works afterwards
+                assert torch.isfinite(out).all(), name           # garbage in must not become NaN/inf out
+                if name != "length field too long":              # (that file still holds the whole payload)
+                    assert not torch.equal(out, ref), name       # and must not be mistaken for the intact picture
+                outcomes[name] = "pixels"
+            except (ValueError, RuntimeError) as e:
+                outcomes[name] = type(e).__name__
+        assert set(outcomes) == set(cases), outcomes
+        open(fn, "wb").write(good)       # and the coder still works afterwards, bit for bit
         again = coder.decompress(fn, padding=64, q_index=3)["x_hat"]
-        assert torch.isfinite(again).all()
+        assert torch.equal(again, ref)
 
 
 def test_gop4_448x256_vs_reference(setup):
