@@ -49,7 +49,8 @@ int64_t pmctf_conv2d_packed_bias_size(int Cout);
  * "SPLIT" 0/1 cut the partial last round of 8x32 tiles into 4x16 tiles, "BIGPX" smallest plane given 8x32 tiles,
  * "V1"/"V2" force the single-buffer / pipelined kernel, "RES" 0/1/2 resident-patch kernel for the
  * cout-split planes (off / one cout tile / all cout tiles per workgroup), "MSPLIT_NT" 1/2/4 tile rows per wave on the
- * cout-split planes, "C16" 0/1 persistent 16->16 kernel with "C16_WGS" workgroups at most. */
+ * cout-split planes, "C16" 0/1 persistent 16->16 kernel with "C16_WGS" workgroups at most, "NBUF1" 0/1 single patch buffer
+ * (three workgroups per CU) for the wave-private kernel on layers of at most 64 couts. */
 int pmctf_conv2d_set_option(const char *name, long value);
 
 /* nn.Conv2d forward (groups=1, zero padding), optionally fused with what follows it

@@ -336,8 +336,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
 // and never synchronises with the other waves of the workgroup (the LDS operations of one wave are ordered), so the
 // two waves sharing a SIMD drift apart and keep the matrix pipe busy across chunk boundaries.  Same arithmetic and
 // sum order as the other variants.  The workgroup (4 waves = 8x32 pixels) only groups waves for dispatch.
-template <int MT, int MAXP>
-__global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
+// NBUF = 2: double-buffered patch (62 KB of LDS per workgroup for 3x3: two workgroups per CU, what the 238-VGPR
+// 112-cout instance can use anyway).  NBUF = 1 (narrow layers, <= 168 VGPRs): one buffer per wave — the next chunk is
+// written after the last read of the current one has been issued, in-order LDS makes that safe — so that THREE workgroups
+// fit a CU and a third wave per SIMD covers the shorter chunks' staging.
+template <int MT, int MAXP, int NBUF = 2>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_mfma_wave_kernel(ConvArgs a) {
     constexpr int NT = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
     const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
     const int taps = a.KH * a.KW;
     const int bufsz = LH * LW * CP;
-    float *wlds = lds + wave * 2 * bufsz;
+    float *wlds = lds + wave * NBUF * bufsz;
 
     f32x4 acc[MT][NT];
     {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
     // (or the next tap's first k-step), so every LDS read is issued one full k-step (MT*NT MFMAs) ahead of its use.
     float b0[NT], b1[NT];
     for (int cb = 0; cb < a.ncb; ++cb) {
-        const float *cur = wlds + (cb & 1) * bufsz;
+        const float *cur = wlds + (NBUF == 2 ? (cb & 1) * bufsz : 0);
         const bool more = cb + 1 < a.ncb;
         if (more) fetch(cb + 1);
 #pragma unroll
@@ -460,8 +464,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_wave_kernel(ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
         }
-        // the other buffer was last read in chunk cb-1 by this same wave: in-order LDS makes the overwrite safe
-        if (more) stash(wlds + ((cb + 1) & 1) * bufsz);
+        // the other buffer was last read in chunk cb-1 by this same wave (NBUF = 1: this buffer, all of whose reads have
+        // been issued by now): in-order LDS makes the overwrite safe
+        if (more) stash(wlds + (NBUF == 2 ? ((cb + 1) & 1) * bufsz : 0));
     }
 
     const bool vec = (a.Cout & 3) == 0;
@@ -752,7 +757,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -806,6 +811,12 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         if (MT >= 4 && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+            if constexpr (MT <= 4) {
+                if (knob("NBUF1") != 0) {       // narrow layers: single patch buffer, three workgroups per CU
+                    PM_LAUNCH((conv_mfma_wave_kernel<MT, 7, 1>), grid, dim3(256), wsmem / 2, st, b);
+                    return pm_launch_status();
+                }
+            }
             static std::once_flag once_w;
             allow_big_lds(conv_mfma_wave_kernel<MT, 7>, once_w);
             PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
