@@ -281,7 +281,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 GOP-{args.gop} q_index={args.q_index} full pMCTF encode "
                                    f"(write_stream, skip_decoding), num_me_stages={net.num_me_stages}",
-                       "schedule": sched_text[args.schedule],
+                       "schedule": "pairs of each temporal stage spread over the ranks (encode_one_stage per pair, motion "
+                                   "context relayed rank to rank, one all-gather per stage)"
+                       if (args.shard == "pairs" and world > 1) else sched_text[args.schedule],
                        "frames_per_step": args.gop * args.inflight, "gops_in_flight_per_gpu": args.inflight,
                        "parallelism": f"gop-dp{world}" if args.shard == "gops" else f"pair-shard{world}",
                        "weights": "deterministic synthetic (pmctf_synth seed 0)"},
