@@ -371,3 +371,32 @@ def test_range_coder_random_tables_property():
         assert np.array_equal(out, sym)
 
     run()
+
+
+def test_deferred_values_semantics():
+    """pMCTF.hip.deferred (pure Python): what the drop-in path hands back instead of finished results.  Arithmetic on a
+    deferred number keeps deferring (the harness's `curr_bits = r["bit_H"] + r["bit_ME"]`, `curr_bits / pixels`);
+    anything that needs the value forces it exactly once; torch functions and attribute access force a deferred tensor."""
+    from pMCTF.hip.deferred import Deferred, DeferredTensor, is_pending, unwrap
+    calls = []
+
+    def make(v):
+        return lambda: (calls.append(v), v)[1]
+    a, b = Deferred(make(1000.0)), Deferred(make(24.0))
+    bits = a + b
+    bpp = bits / 512
+    total = 0.0 + bits                      # generate_log_json-style accumulation
+    assert calls == [] and is_pending(a) and isinstance(bpp, Deferred) and isinstance(total, Deferred)
+    assert float(bpp) == 2.0 and calls == [1000.0, 24.0]
+    assert float(total) == 1024.0 and calls == [1000.0, 24.0]          # forced once
+    assert not is_pending(a) and f"{bits:.1f}" == "1024.0" and bits > 1000 and bits == 1024.0
+    assert not isinstance(bits, torch.Tensor)
+    made = []
+    t = DeferredTensor(lambda: (made.append(1), torch.arange(6.0).reshape(1, 1, 2, 3))[1], ready=lambda: bool(made))
+    assert is_pending(t)
+    assert torch.round(t).shape == (1, 1, 2, 3) and made == [1]        # a torch function forces it
+    assert t.shape == (1, 1, 2, 3) and float(t[0, 0, 1, 2]) == 5.0 and float((t + 1).sum()) == 21.0
+    assert unwrap({"x": [t, None, 3]})["x"][0] is t.force()
+    assert np.asarray(t).shape == (1, 1, 2, 3)
+    d = Deferred(lambda: {"H": b"abc"})
+    assert d["H"] == b"abc" and "H" in d and len(d) == 1
