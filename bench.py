@@ -9,6 +9,7 @@ reference's harness (test_pMCTF_flex.py:214-223) — 15 pairs + the final L fram
 are deferred and the pairs of a temporal stage coded as one batch, pMCTF.hip.deferred; the harness cannot tell.)  In the
 same run, after the timed region, rank 0 also measures (auxiliary figures, never `value`):
   * `eager_pair_by_pair` — the same loop with deferral off (every call finished before it returns);
+  * `luma_chroma_two_streams` — the default loop with the luma and chroma coders on two HIP streams;
   * `stage_batched`     — all pairs of a temporal stage in one call (pMCTF.encode_stage_pairs): same files and bits,
                           larger launches;
   * `cross_gop_batched` — the same with stage s of K closed GOPs in one call (pmctf_gop.encode_gops_batched);
@@ -320,6 +321,19 @@ def main():
                         "steps": aux_steps, "schedule": "encode_one_stage pair by pair, every call finished before it returns",
                         "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"],
                         "roofline": roofline_of(ev_e, kname["pairs"] + ", f32 MFMA 16x16x4", traffic)}
+                if args.schedule == "pairs" and net.lazy_stages:
+                    # luma and chroma coders of a stage on two HIP streams (independent once the motion is known): the
+                    # small launches of one fill the tails of the other.  Off in the headline run because kernels that
+                    # share the GPU spoil per-kernel event timing (the roofline probe).
+                    eng = net.engine()
+                    eng.multi_stream, keep_mp = True, eng.multi_stream_max_pairs
+                    eng.multi_stream_max_pairs = 1 << 20
+                    t_m, _ = timed(step_main, aux_steps, 1)
+                    eng.multi_stream, eng.multi_stream_max_pairs = False, keep_mp
+                    out["luma_chroma_two_streams"] = {
+                        "value": args.gop * aux_steps / t_m, "unit": "frames/s", "ms_per_step": t_m / aux_steps * 1e3,
+                        "steps": aux_steps, "schedule": sched_text["pairs"] + "; luma / chroma coders on two HIP streams",
+                        "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"]}
                 if args.schedule == "pairs":
                     def batched():
                         last["enc"] = pmctf_gop.encode_gop_batched(net, frames, H, W, args.q_index, tmp)

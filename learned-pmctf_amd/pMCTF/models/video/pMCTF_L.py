@@ -144,11 +144,12 @@ class pMCTF(nn.Module):
         if not recs:
             return
         key, dpb0, q["key"], q["dpb0"] = q["key"], q["dpb0"], None, None
-        code_lt, stage_idx, q_index, psize, pic_width, pic_height = key[:6]
+        code_lt, stage_idx, q_index, psize, pic_width, pic_height, me_downsample = key[:7]
         try:
             results, _ = self.encode_stage_pairs([r["pair"] for r in recs], code_lt, dpb0, [r["path"] for r in recs],
                                                  pic_width, pic_height, psize=psize, stage_idx=stage_idx, q_index=q_index,
-                                                 chain_reset=[i for i, r in enumerate(recs) if r["reset"] and i > 0])
+                                                 chain_reset=[i for i, r in enumerate(recs) if r["reset"] and i > 0],
+                                                 me_downsample=me_downsample)
         except BaseException as e:
             for r in recs:
                 r["error"] = e
@@ -156,13 +157,14 @@ class pMCTF(nn.Module):
         for r, res in zip(recs, results):
             r["result"] = res
 
-    def _defer(self, ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx, q_index):
+    def _defer(self, ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx, q_index,
+               me_downsample=1):
         q = self._queue()
         # inputs produced by pairs that are still pending (a later temporal stage): they are needed now
         if any(is_pending(t) for t in (*ref_frame, *cur_frame)):
             self.flush()
         ref_frame, cur_frame = unwrap(list(ref_frame)), unwrap(list(cur_frame))
-        key = (code_lt, stage_idx, q_index, psize, pic_width, pic_height, tuple(ref_frame[0].shape),
+        key = (code_lt, stage_idx, q_index, psize, pic_width, pic_height, me_downsample, tuple(ref_frame[0].shape),
                tuple(ref_frame[1].shape), ref_frame[0].device)
         mvf, rmy = dpb["mv_feature"], dpb["ref_mv_y"]
         last = q["pairs"][-1] if q["pairs"] else None
@@ -263,7 +265,7 @@ class pMCTF(nn.Module):
 
     @torch.no_grad()
     def encode_stage_pairs(self, pairs, code_lt, dpb, output_paths, pic_width, pic_height, psize=128, stage_idx=0,
-                           q_index=0, chain_reset=()):
+                           q_index=0, chain_reset=(), me_downsample=1):
         """All pairs of one temporal stage in one call: pairs = [(ref_frame, cur_frame)], output_paths = ["k.bin"].
         Returns ([result dict per pair, exactly what encode_one_stage(skip_decoding=True) returns for it], dpb for a
         following call).  The motion codec runs pair after pair (its context is a chain, pMCTF_L.py:448-495); the
@@ -286,7 +288,8 @@ class pMCTF(nn.Module):
         for i, ((ref_y, _), (cur_y, _)) in enumerate(pairs):
             if i in chain_reset:
                 dpb = {"mv_feature": None, "ref_mv_y": None}
-            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index)
+            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index,
+                                 me_downsample=me_downsample)
             jobs[i]["mv"] = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0),
                                              output_paths[i].replace(".bin", "_mv.bin"), keep)
             dpb = {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
@@ -433,10 +436,9 @@ class pMCTF(nn.Module):
         delivers the context once the motion has been estimated, and `on_dpb(dpb)` is called with the NEXT pair's
         context as soon as the motion codec has produced it, before the subbands are coded."""
         self._check_ds(me_downsample)
-        if (self.lazy_stages and output_path is not None and skip_decoding and me_downsample == 1 and on_dpb is None
-                and not callable(dpb)):
+        if self.lazy_stages and output_path is not None and skip_decoding and on_dpb is None and not callable(dpb):
             return self._defer(ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx,
-                               q_index)
+                               q_index, me_downsample)
         self.flush()
         ref_frame, cur_frame = unwrap((list(ref_frame), list(cur_frame)))
         if not callable(dpb):

@@ -994,6 +994,18 @@ def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
         assert sorted(os.listdir(td)) == ["1.bin", "1_C_main.bin", "1_mv.bin", "3.bin", "3_C_main.bin", "3_mv.bin"]
         assert float(r2["bit_H"] + r2["bit_ME"]) == ref["bits"][3]
         assert torch.equal(torch.round(r2["H_t"]), torch.round(ref["frames_coded"][3][0]))     # torch functions force
+    # motion at reduced resolution (the content-adaptive harness's calls) is deferred and batched the same way
+    net.lazy_stages = False
+    with tempfile.TemporaryDirectory() as td:
+        ref2 = pmctf_gop.encode_gop(net, fr[:4], H, W, 3, td, me_downsample=2)
+        ref2_files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+    net.lazy_stages = True
+    del calls[:]
+    with tempfile.TemporaryDirectory() as td:
+        lazy2 = pmctf_gop.encode_gop(net, fr[:4], H, W, 3, td, me_downsample=2)
+        assert calls == [2, 1]
+        assert {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))} == ref2_files
+    assert lazy2["bits"] == ref2["bits"]
     net.encode_stage_pairs = orig
 
 
