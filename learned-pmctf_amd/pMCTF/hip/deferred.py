@@ -29,7 +29,10 @@ class Deferred:
 
     def force(self):
         if not self._done:
-            self._value = self._thunk()
+            v = self._thunk()
+            while isinstance(v, Deferred):         # a deferred result of a deferred producer
+                v = v.force()
+            self._value = v
             self._done = True
             self._thunk = self._ready = None
         return self._value

@@ -14,6 +14,7 @@ reference's own version raises KeyError, SURVEY F3 — here it returns what it w
 NotImplementedError): training-mode forward.  me_downsample in {1, 2, 4, 8} is supported everywhere (motion
 estimated and coded at reduced resolution).
 """
+import contextlib
 import os
 import os.path as osp
 import threading
@@ -135,10 +136,24 @@ class pMCTF(nn.Module):
             q = self._tls.q = {"key": None, "pairs": [], "dpb0": None}
         return q
 
-    def flush(self, q=None):
-        """Code every pair collected so far (one encode_stage_pairs call) and resolve their deferred results; their
-        bitstream files exist from here on.  Called implicitly by every use of a deferred value and by every other
-        entry point of the model."""
+    def _pending_files(self):
+        p = getattr(self._tls, "files", None)
+        if p is None:
+            p = self._tls.files = []
+        return p
+
+    def flush(self):
+        """Code every pair collected so far and wait for the range-coder threads: the bitstream files of every pair handed
+        over so far exist from here on.  (Using a deferred bit count waits for that pair's files; using a deferred
+        tensor only enqueues the GPU work.)"""
+        self._run_pending()
+        files, self._tls.files = self._pending_files(), []
+        for f in files:
+            f.result()
+
+    def _run_pending(self, q=None):
+        """Enqueue the GPU work of every pair collected so far (one encode_stage_pairs call); does not wait for the
+        range coder."""
         q = self._queue() if q is None else q
         recs, q["pairs"] = q["pairs"], []
         if not recs:
@@ -149,7 +164,7 @@ class pMCTF(nn.Module):
             results, _ = self.encode_stage_pairs([r["pair"] for r in recs], code_lt, dpb0, [r["path"] for r in recs],
                                                  pic_width, pic_height, psize=psize, stage_idx=stage_idx, q_index=q_index,
                                                  chain_reset=[i for i, r in enumerate(recs) if r["reset"] and i > 0],
-                                                 me_downsample=me_downsample)
+                                                 me_downsample=me_downsample, wait_files=False)
         except BaseException as e:
             for r in recs:
                 r["error"] = e
@@ -162,7 +177,7 @@ class pMCTF(nn.Module):
         q = self._queue()
         # inputs produced by pairs that are still pending (a later temporal stage): they are needed now
         if any(is_pending(t) for t in (*ref_frame, *cur_frame)):
-            self.flush()
+            self._run_pending()
         ref_frame, cur_frame = unwrap(list(ref_frame)), unwrap(list(cur_frame))
         key = (code_lt, stage_idx, q_index, psize, pic_width, pic_height, me_downsample, tuple(ref_frame[0].shape),
                tuple(ref_frame[1].shape), ref_frame[0].device)
@@ -171,7 +186,7 @@ class pMCTF(nn.Module):
         chained = last is not None and mvf is last["out"]["dpb"]["mv_feature"] and rmy is last["out"]["dpb"]["ref_mv_y"]
         fresh = mvf is None and rmy is None
         if q["pairs"] and (key != q["key"] or not (chained or fresh) or len(q["pairs"]) >= self.lazy_max_pairs):
-            self.flush()
+            self._run_pending()
             chained = False
         if not q["pairs"]:
             q["key"] = key
@@ -184,7 +199,7 @@ class pMCTF(nn.Module):
                 if rec["result"] is None:
                     if rec["error"] is not None:
                         raise RuntimeError("the deferred encode of this pair failed") from rec["error"]
-                    self.flush(q)
+                    self._run_pending(q)
                 v = rec["result"][k]
                 return v[sub] if sub is not None else v
             return thunk
@@ -265,7 +280,7 @@ class pMCTF(nn.Module):
 
     @torch.no_grad()
     def encode_stage_pairs(self, pairs, code_lt, dpb, output_paths, pic_width, pic_height, psize=128, stage_idx=0,
-                           q_index=0, chain_reset=(), me_downsample=1):
+                           q_index=0, chain_reset=(), me_downsample=1, wait_files=True):
         """All pairs of one temporal stage in one call: pairs = [(ref_frame, cur_frame)], output_paths = ["k.bin"].
         Returns ([result dict per pair, exactly what encode_one_stage(skip_decoding=True) returns for it], dpb for a
         following call).  The motion codec runs pair after pair (its context is a chain, pMCTF_L.py:448-495); the
@@ -285,15 +300,40 @@ class pMCTF(nn.Module):
         jobs = [dict() for _ in range(P)]
         mvs = []
         chain_reset = set(chain_reset)
-        for i, ((ref_y, _), (cur_y, _)) in enumerate(pairs):
-            if i in chain_reset:
-                dpb = {"mv_feature": None, "ref_mv_y": None}
-            mv = eng.compress_mv(c(ref_y), c(cur_y), dpb, stage_idx=stage_idx, q_index=q_index,
-                                 me_downsample=me_downsample)
-            jobs[i]["mv"] = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0),
-                                             output_paths[i].replace(".bin", "_mv.bin"), keep)
-            dpb = {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
-            mvs.append((mv, dpb))
+        # The motion chain of this stage (SpyNet + motion codec per pair: small, latency-bound launches, 7 % of the work)
+        # needs nothing of the previous stage but its uncoded L frames, which exist long before that stage's entropy
+        # networks have finished.  It therefore runs on a side stream that waits only for the event recorded behind the
+        # previous stage's temporal lifting, and overlaps with the previous stage's remaining work; the lifting and the
+        # spatial coders of this stage (main stream) wait for it.
+        main = torch.cuda.current_stream(dev)
+        lumas = [c(t) for (ry, _), (cy, _) in pairs for t in (ry, cy)]
+        overlap = eng.motion_overlap
+        if overlap:
+            side = eng.motion_stream
+            if eng.lt_event is not None and all(t is eng.lt_tensor or t._base is eng.lt_tensor for t in lumas):
+                side.wait_event(eng.lt_event)        # inputs are slices of the previous stage's batched L_t
+            else:
+                side.wait_stream(main)
+            for t in lumas:
+                t.record_stream(side)
+            if dpb["mv_feature"] is not None:
+                side.wait_stream(main)
+        ctx = torch.cuda.stream(side) if overlap else contextlib.nullcontext()
+        with ctx:
+            for i in range(P):
+                if i in chain_reset:
+                    dpb = {"mv_feature": None, "ref_mv_y": None}
+                mv = eng.compress_mv(lumas[2 * i], lumas[2 * i + 1], dpb, stage_idx=stage_idx, q_index=q_index,
+                                     me_downsample=me_downsample)
+                jobs[i]["mv"] = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0),
+                                                 output_paths[i].replace(".bin", "_mv.bin"), keep)
+                dpb = {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
+                mvs.append((mv, dpb))
+        if overlap:
+            main.wait_stream(side)
+            for mv, _ in mvs:
+                for k in ("mv_hat", "mv_feature", "mv_y_hat"):
+                    mv[k].record_stream(main)
 
         def paths_for(i, kind, chroma):
             base = osp.basename(output_paths[i])
@@ -345,9 +385,20 @@ class pMCTF(nn.Module):
             luma["finish"]()
             chroma["finish"]()
         results = []
+        pending = self._pending_files()
+        pending[:] = [f for f in pending if not f.done()]
         for i in range(P):
-            done = {k: j.result() for k, j in jobs[i].items()}
-            bits = {k: v[0] * 8.0 for k, v in done.items()}
+            # Bit counts are the sizes of the files the range-coder threads are still writing.  wait_files=True (a direct
+            # call): wait for them here.  From the deferred drop-in path they stay deferred too, so that the host goes on
+            # to enqueue the next stage while this one is still being coded (what lets its motion chain overlap).
+            if wait_files:
+                done = {k: j.result() for k, j in jobs[i].items()}
+                bits = {k: v[0] * 8.0 for k, v in done.items()}
+            else:
+                pending.extend(jobs[i].values())
+                done = {k: (Deferred(lambda j=j: j.result()[0]), Deferred(lambda j=j: j.result()[1]),
+                            Deferred(lambda j=j: j.result()[2])) for k, j in jobs[i].items()}
+                bits = {k: Deferred(lambda j=j: j.result()[0] * 8.0) for k, j in jobs[i].items()}
             mv, dpb_i = mvs[i]
             ys, cs = slice(i, i + 1), slice(2 * i, 2 * i + 2)
             r = {"L_t": (luma["L_t_hat"] if code_lt else luma["L_t"])[ys], "H_t": luma["H_t_hat"][ys],
