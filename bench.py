@@ -258,9 +258,9 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
     kname = {"pairs": "3x3 112->112 conv on 576x960 luma subband planes (N per launch = pairs coded together): "
-                      "conv_mfma_wave_kernel<7,7> for the rows that fill whole rounds of workgroups + "
+                      "conv3x3s1_wave_kernel<7,2> for the rows that fill whole rounds of workgroups + "
                       "conv_mfma_pipe_kernel<7,1,1,6> for the remainder",
-             "stages": "conv_mfma_wave_kernel<7,7> (3x3 112->112 on 576x960 subband planes, batch = pairs of the stage)"}
+             "stages": "conv3x3s1_wave_kernel<7,2> (3x3 112->112 on 576x960 subband planes, batch = pairs of the stage)"}
     roofline = roofline_of(events, kname[args.schedule] + ", f32 MFMA 16x16x4", traffic)
     sched_text = {"pairs": "encode_one_stage called pair by pair, the reference harness's loop (test_pMCTF_flex.py:214-223); "
                            "results are deferred and the pairs of a temporal stage coded as one batch inside the model "

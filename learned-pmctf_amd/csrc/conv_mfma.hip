@@ -503,6 +503,179 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_mfma_wave_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 specialisation of the barrier-free wave-private variant (the shape of 70 % of the encode's FLOPs).
+// On gfx950 a v_mfma_f32_16x16x4_f32 and vector-ALU instructions do NOT overlap on a SIMD (tools/mfma_valu_overlap.hip:
+// time = matrix cycles + vector cycles, within a wave and across the waves of a SIMD), so every v_mov / address
+// computation of the inner loop is matrix time lost.  Here the nine taps are unrolled (the two weight-fragment sets
+// alternate without copies, one copy per 16-channel chunk remains), every LDS address is ONE per-wave base register plus an
+// immediate, the staging slots' global offsets and bounds are computed once per tile, and the 16-channel chunk advances
+// a scalar base.  Same arithmetic and sum order as every other variant (chunk, ky, kx, ci ascending).
+template <int MT, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(ConvArgs a) {
+    constexpr int NT = 4, LH = 6, LW = 18, MAXP = 7;
+    constexpr int BUFSZ = LH * LW * CP;
+    constexpr int E = LH * LW * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mtile0 = blockIdx.z * MT;
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = a.oy_base + ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
+    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
+    float *wlds = lds + wave * NBUF * BUFSZ;
+
+    f32x4 acc[MT][NT];
+    {
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+        }
+    }
+    // staging: lane owns float4 slots e = lane + 64*j of this wave's patch (pixel e>>2, channel quad e&3); bounds and
+    // byte offsets inside image n are fixed for the tile, slots outside the image stay zero for ever
+    bool ok[MAXP];
+    unsigned goff[MAXP];
+    f32x4 pre[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = lane + 64 * j;
+        const int pix = e >> 2, part = e & 3;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        ok[j] = e < E && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[j] = ok[j] ? (unsigned)(((gy * a.W + gx) * a.Cin + part * 4) * 4) : 0u;
+        pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char *xn = (const char *)(a.x + (size_t)n * a.H * a.W * a.Cin);
+    auto fetch = [&](int cb) {
+        const char *base = xn + cb * (CB * 4);
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+            if (ok[j]) pre[j] = *(const f32x4 *)(base + goff[j]);
+    };
+    float *sdst = wlds + (lane >> 2) * CP + (lane & 3) * 4;
+    auto stash = [&](int buf) {
+        float *d0 = sdst + buf * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            if (64 * j + 63 < E || lane + 64 * j < E) {
+                float2 *dst = (float2 *)(d0 + j * 16 * CP);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * 9 * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
+    const long wsteps = (long)a.ncb * 9;
+    f32x4 wf[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wf[0][mt] = *(const f32x4 *)(wq + mt * 256);
+    fetch(0);
+    stash(0);
+    long wstep = 0;
+    const float *bl = wlds + (lane & 15) * CP + (lane >> 4);
+    float b0[NT], b1[NT];
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        const float *cur = bl + (NBUF == 2 ? (cb & 1) * BUFSZ : 0);
+        const bool more = cb + 1 < a.ncb;
+        if (more) fetch(cb + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[nt * LW * CP];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * LW + (t % 3)) * CP;
+            const int tnext = (((t + 1) / 3) * LW + ((t + 1) % 3)) * CP;
+            ++wstep;
+            {   // next tap's weight fragments into the other set (the last step re-reads its own block: no branch)
+                const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) wf[(t + 1) & 1][mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = cur[nt * LW * CP + toff + 4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[nt * LW * CP + toff + 8];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][1], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b1[nt] = cur[nt * LW * CP + toff + 12];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][2], b0[nt], acc[mt][nt], 0, 0, 0);
+            if (t < 8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[nt * LW * CP + tnext];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][3], b1[nt], acc[mt][nt], 0, 0, 0);
+        }
+        // nine taps: the next chunk's first fragments arrived in set 1
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
+        // the other buffer was last read in chunk cb-1 by this same wave (NBUF = 1: this buffer, all of whose reads have
+        // been issued by now): in-order LDS makes the overwrite safe
+        if (more) stash(NBUF == 2 ? ((cb + 1) & 1) : 0);
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + nt, ox = ox0 + (lane & 15);
+        if (oy >= a.oy_end || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
+            if (co >= a.Cout) continue;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (co + i < a.Cout) {
+                        float s = v[i];
+                        if (a.res1) s = s + a.res1[pbase + co + i];
+                        if (a.res2) s = s + a.res2[pbase + co + i];
+                        a.y[pbase + co + i] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Resident-patch variant for small planes (same arithmetic, same sum order): the workgroup stages the input patch of
 // its 4x16 tile for ALL input channels at once (one global-load latency instead of one per 16-channel chunk, a single
 // barrier), then every wave runs its 16 pixels x MT cout tiles straight through.  Small planes are latency-bound in
@@ -757,7 +930,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -811,11 +984,20 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         if (MT >= 4 && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+            const bool k33 = a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
+                             (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32);
             if constexpr (MT <= 4) {
                 if (knob("NBUF1") != 0) {       // narrow layers: single patch buffer, three workgroups per CU
-                    PM_LAUNCH((conv_mfma_wave_kernel<MT, 7, 1>), grid, dim3(256), wsmem / 2, st, b);
+                    if (k33) PM_LAUNCH((conv3x3s1_wave_kernel<MT, 1>), grid, dim3(256), wsmem / 2, st, b);
+                    else PM_LAUNCH((conv_mfma_wave_kernel<MT, 7, 1>), grid, dim3(256), wsmem / 2, st, b);
                     return pm_launch_status();
                 }
+            }
+            if (k33) {
+                static std::once_flag once_k;
+                allow_big_lds(conv3x3s1_wave_kernel<MT, 2>, once_k);
+                PM_LAUNCH((conv3x3s1_wave_kernel<MT, 2>), grid, dim3(256), wsmem, st, b);
+                return pm_launch_status();
             }
             static std::once_flag once_w;
             allow_big_lds(conv_mfma_wave_kernel<MT, 7>, once_w);

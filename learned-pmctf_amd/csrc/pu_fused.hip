@@ -98,8 +98,20 @@ __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int
     }
 }
 
+// per-phase cycle counters for tools/pu_prof.hip (compiled in only there)
+#ifdef PMCTF_PU_PROFILE
+static size_t pu_extra_lds = 0;
+__device__ unsigned long long pu_prof[8];
+#define PU_STAMP(i) do { if (tid == 0) { const long long t_ = clock64(); atomicAdd(&pu_prof[i], (unsigned long long)(t_ - t_prev_)); t_prev_ = t_; } } while (0)
+#else
+#define PU_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef PMCTF_PU_PROFILE
+    long long t_prev_ = clock64();
+#endif
     float *in = lds + LDS_IN, *sk = lds + LDS_SK, *A1 = lds + LDS_A1, *A2 = lds + LDS_A2;
     float *A3 = A1;                                   // layer-3 output reuses the (dead) tanh(c1) buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         sk[e] = s;
     }
     __syncthreads();
+    PU_STAMP(0);
 
     // ---- P1 (vector ALU): tanh(conv1) on the 14x38 region.  A thread owns up to three pixels; the 16 couts go in four
     // groups of four so that a group's 36 weights + 4 biases are wave-uniform scalars while all pixels use them.
@@ -178,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         }
     }
     __syncthreads();
+    PU_STAMP(1);
 
     // ---- P2 (matrix cores): tanh(conv2(tanh c1)) on the 12x36 region
     mfma_layer(A1, R1W, R2W, N2, a.w2p, a.b2p, wave, lane, [&](int idx, int r, int c, f32x4 acc) {
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         dst[1] = make_float2(v[2], v[3]);
     });
     __syncthreads();
+    PU_STAMP(2);
 
     // ---- P3 (matrix cores): conv3(.) + c1 on the 10x34 region; c1 re-evaluated from the input tile (same nine fmaf)
     float w1g[4][9], b1g[4];                  // conv1 weights of this lane's four couts (4*(lane>>4) ..)
@@ -222,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         dst[1] = make_float2(v[2], v[3]);
     });
     __syncthreads();
+    PU_STAMP(3);
 
     // ---- P4 (vector ALU): conv4 (16 -> 1) on the 8x32 tile + the lifting arithmetic; thread = output pixel
     {
@@ -251,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
             a.out[o] = res;
         }
     }
+    PU_STAMP(4);
 }
 
 }  // namespace
@@ -276,6 +293,10 @@ extern "C" int pmctf_predict_update_fused_f32(const float *x, const float *other
         return true;
     }();
     (void)attr;
+#ifdef PMCTF_PU_PROFILE
+    PM_LAUNCH(pu_fused_kernel, dim3((unsigned)blocks), dim3(256), LDS_FLOATS * sizeof(float) + pu_extra_lds, (hipStream_t)stream, a);
+#else
     PM_LAUNCH(pu_fused_kernel, dim3((unsigned)blocks), dim3(256), LDS_FLOATS * sizeof(float), (hipStream_t)stream, a);
+#endif
     return pm_launch_status();
 }

@@ -35,7 +35,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("pu 16->1 3x3 1152x1920", 1, 1152, 1920, 16, 1, 3, 1, 1),
     ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
     ("lstm 32->32 576x960", 1, 576, 960, 32, 32, 3, 1, 1),
-]
+] + [("nscan %dx576x960" % n, n, 576, 960, 112, 112, 3, 1, 1) for n in (2, 3, 4, 6, 8, 12, 16)] \
+  + [("nscan64 %dx1152x1920" % n, n, 1152, 1920, 64, 64, 3, 1, 1) for n in (2, 4, 8)]
 
 
 def main():
@@ -54,12 +55,15 @@ def main():
         b = torch.randn(Cout)
         conv = ops.Conv2d(w, b, S, (P, P))
         x = torch.randn(N, H, W, Cin, device="cuda")
+        if os.environ.get("BENCH_RELU_INPUT"):     # activations as a ReLU leaves them (half zeros)
+            x = torch.relu(x)
         y = conv(x)
+        res = torch.randn_like(y) if os.environ.get("BENCH_RES") else None      # residual-add epilogue
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            conv(x, out=y)
+            conv(x, res1=res, out=y)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps

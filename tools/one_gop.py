@@ -20,20 +20,4 @@ def match(conv, x, stride):
     return True
 with torch.no_grad():
     pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
-    probe = {"match": match, "events": []}
-    ops.CONV_PROBE = probe
     pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
-    ops.CONV_PROBE = None
-agg = collections.OrderedDict()
-for s, (e0, e1, fl) in zip(sigs, probe["events"]):
-    a = agg.setdefault(s, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
-tot = sum(a[1] for a in agg.values())
-print(f"total conv ms {tot:.1f}  total TFLOP {sum(a[2] for a in agg.values())/1e12:.1f}")
-for s, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    (N, h, w, ci), co, k, st = s
-    print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{st}  n={a[0]:5d} {a[1]:8.1f} ms ({a[1]/tot*100:4.1f}%) {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
-if len(sys.argv) > 1:                       # per-launch durations of one signature, in launch order: N H W Cin Cout
-    want = tuple(int(v) for v in sys.argv[1:5])
-    d = [round(e0.elapsed_time(e1) * 1e3) for s, (e0, e1, fl) in zip(sigs, probe["events"])
-         if s[0] == want and s[1] == int(sys.argv[5]) and s[2] == 3 and s[3] == 1]
-    print("per-launch us:", d)
