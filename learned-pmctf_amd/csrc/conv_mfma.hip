@@ -930,7 +930,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -981,7 +981,7 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     if (smem > 160 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
     if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
-        if (MT >= 4 && wave_eligible(a)) {
+        if ((MT >= 4 || (MT == 1 && knob("WAVE_SMALL") != 0)) && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
             const bool k33 = a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
@@ -1085,6 +1085,14 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
             if (rc != PMCTF_EINVAL) return rc;
         }
         const long mnt = knob("MSPLIT_NT");
+        // 3x3 stride 1 whose planes fill 8x32 tiles to >= 90 %: the barrier-free wave-private kernel with one cout tile
+        // per workgroup (a wave owns a 4x16 tile and its own patch; 4x fewer, 4x longer wave tasks than the 4x16
+        // workgroup tiles below and no barriers).  tools/bench_conv.py: 144x240 79 -> 103 TFLOP/s, 8x72x120 81 -> 107,
+        // 2x72x120 67 -> 87; planes that fit the tiles badly (36x60: 18 % padding) stay on the fine tiles.
+        if (knob("WAVE_SMALL") != 0 && mnt == 1 && a.KH == 3 && a.KW == 3 && a.S == 1 && wave_eligible(a)) {
+            const long padded = (long)((a.Ho + 7) / 8) * 8 * ((a.Wo + 31) / 32) * 32;
+            if (padded * 10 <= (long)a.Ho * a.Wo * 11) return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
+        }
         if (mnt == 2) return launch<1, 2, 1>(a, MTP * MB, st, 0, a.Ho);
         if (mnt == 4 && a.S == 1) return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
         return launch<1, 1, 1>(a, MTP * MB, st, 0, a.Ho);
