@@ -913,6 +913,137 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// 1x1 convolution (stride 1, no padding) as a plain GEMM over the flattened pixels: the MV codec's 192 <-> 768 layers
+// on 72x120 planes and the 64 <-> 256 layers on 576x960.  The tap-oriented kernels above stage a 16-channel chunk per
+// barrier pair and get 4*MT matrix instructions out of it for a 1x1 filter: they spend their time waiting.  Here a
+// workgroup stages 64 channels of 16*NT pixels at a time (double-buffered, one barrier per 64 channels), every wave
+// multiplies all the pixels by its own MTW cout tiles (16*MTW*NT matrix instructions per k-chunk and wave), LDS
+// addresses are one register plus immediates.  Same sum order as everywhere: acc = bias, channels ascending.
+template <int MTW, int NT>
+__global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int tiles_total) {
+    constexpr int PX = 16 * NT, KC = 64, KP = KC + 2, SLOTS = PX * (KC / 4) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long p0 = (long)blockIdx.x * PX;
+    const int t0 = (blockIdx.y * WAVES + wave) * MTW;            // first cout tile of this wave
+    const int nchunk = (a.ncb + 3) >> 2;
+
+    f32x4 acc[MTW][NT];
+    const float *wt[MTW];                                        // fragment base of each tile: + cb * mtp * 256 per chunk
+    bool live[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int t = t0 + i;
+        live[i] = t < tiles_total;
+        const int tt = live[i] ? t : 0;
+        const int mb = tt / a.mtp, mtin = tt - mb * a.mtp;
+        wt[i] = a.wp + ((size_t)mb * a.ncb * a.mtp + mtin) * 256 + lane * 4;
+        const f32x4 b = *(const f32x4 *)(a.bp + (size_t)tt * 16 + 4 * (lane >> 4));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[i][nt] = b;
+    }
+    const int wstride = a.mtp * 256;
+
+    // staging: thread owns float4 slots e = tid + 256*j: pixel e >> 4, channel quad e & 15 of the 64-channel chunk
+    f32x4 pre[SLOTS];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int e = tid + 256 * j;
+            const long p = p0 + (e >> 4);
+            const int ch = c * KC + (e & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < P && ch < a.Cin) v = *(const f32x4 *)(a.x + p * a.Cin + ch);
+            pre[j] = v;
+        }
+    };
+    auto stash = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int e = tid + 256 * j;
+            float2 *dst = (float2 *)(buf + (e >> 4) * KP + (e & 15) * 4);
+            dst[0] = make_float2(pre[j].x, pre[j].y);
+            dst[1] = make_float2(pre[j].z, pre[j].w);
+        }
+    };
+    fetch(0);
+    stash(lds);
+    __syncthreads();
+    f32x4 af[2][MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) af[0][i] = *(const f32x4 *)(wt[i]);
+    const float *bl = lds + (lane & 15) * KP + (lane >> 4);
+    for (int c = 0; c < nchunk; ++c) {
+        const float *cur = bl + (c & 1) * (PX * KP);
+        const bool more = c + 1 < nchunk;
+        if (more) fetch(c + 1);
+        const int nsub = a.ncb - 4 * c < 4 ? a.ncb - 4 * c : 4;      // 16-channel blocks in this chunk (uniform)
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            if (sb < nsub) {
+                {   // next 16-channel block's fragments (the last block re-reads its own: no branch)
+                    const int cbn = 4 * c + sb + 1 < a.ncb ? 4 * c + sb + 1 : a.ncb - 1;
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) af[(sb + 1) & 1][i] = *(const f32x4 *)(wt[i] + (size_t)cbn * wstride);
+                }
+                float b[4][NT];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[ks][nt] = cur[nt * 16 * KP + sb * 16 + ks * 4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sb & 1][i][ks], b[ks][nt], acc[i][nt], 0, 0, 0);
+            }
+        }
+        if (nsub & 1) {                                           // odd block count: the prefetched set is set 1
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) af[0][i] = af[1][i];
+        }
+        if (more) stash(lds + ((c + 1) & 1) * (PX * KP));
+        __syncthreads();
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const long p = p0 + nt * 16 + (lane & 15);
+        if (p >= P) continue;
+        const size_t pbase = (size_t)p * a.Cout;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int co = (t0 + i) * 16 + 4 * (lane >> 4);
+            if (!live[i] || co >= a.Cout) continue;
+            f32x4 v = acc[i][nt];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = pm::apply_act(v[k], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (co + k < a.Cout) {
+                        float sv = v[k];
+                        if (a.res1) sv = sv + a.res1[pbase + co + k];
+                        if (a.res2) sv = sv + a.res2[pbase + co + k];
+                        a.y[pbase + co + k] = sv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 // choose cout tiles per workgroup (MT in {1,2,4,7,8}) and the number of M-blocks
 void choose_mt(int Cout, int &MT, int &MB) {
     const int tiles = (Cout + 15) / 16;
@@ -930,7 +1061,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1127,6 +1258,41 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
 }
 
+// 1x1 GEMM launch: 64 pixels per workgroup on large planes, 32 on small ones; as many cout tiles per wave (<= 4) as
+// still leave >= 512 workgroups.
+template <int MTW, int NT>
+int launch_1x1_t(const ConvArgs &a, long P, int tiles, hipStream_t st) {
+    constexpr int PX = 16 * NT;
+    const long gx = (P + PX - 1) / PX;
+    const int gy = (tiles + WAVES * MTW - 1) / (WAVES * MTW);
+    if (gx > 0x7fffffffL) return PMCTF_EINVAL;
+    const size_t smem = (size_t)2 * PX * 66 * sizeof(float);
+    PM_LAUNCH((conv1x1_kernel<MTW, NT>), dim3((unsigned)gx, gy), dim3(256), smem, st, a, P, tiles);
+    return pm_launch_status();
+}
+int launch_1x1(const ConvArgs &a, int tiles, hipStream_t st) {
+    const long P = (long)a.N * a.H * a.W;
+    const bool big = P >= 32768;
+    const long gx = (P + (big ? 63 : 31)) / (big ? 64 : 32);
+    int mtw = 1;
+    for (int m = tiles >= 16 ? 4 : tiles / 4; m >= 1; --m)
+        if (gx * ((tiles + WAVES * m - 1) / (WAVES * m)) >= 512 || m == 1) { mtw = m; break; }
+    if (big) {
+        switch (mtw) {
+        case 4: return launch_1x1_t<4, 4>(a, P, tiles, st);
+        case 3: return launch_1x1_t<3, 4>(a, P, tiles, st);
+        case 2: return launch_1x1_t<2, 4>(a, P, tiles, st);
+        default: return launch_1x1_t<1, 4>(a, P, tiles, st);
+        }
+    }
+    switch (mtw) {
+    case 4: return launch_1x1_t<4, 2>(a, P, tiles, st);
+    case 3: return launch_1x1_t<3, 2>(a, P, tiles, st);
+    case 2: return launch_1x1_t<2, 2>(a, P, tiles, st);
+    default: return launch_1x1_t<1, 2>(a, P, tiles, st);
+    }
+}
+
 }  // namespace
 
 extern "C" int pmctf_conv2d_set_option(const char *name, long value) {
@@ -1191,6 +1357,11 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;
+    if (KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
+        knob("K11") != 0 && MT * MB >= 8) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
+        a.mtp = MT;
+        return launch_1x1(a, MT * MB, st);
+    }
     switch (MT) {
     case 1: return dispatch_tile<1>(a, MB, st);
     case 2: return dispatch_tile<2>(a, MB, st);

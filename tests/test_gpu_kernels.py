@@ -55,6 +55,11 @@ CONV_CASES = [
     (1, 3, 17, 40, 192, 3, 1, 1, 0, 0.0, 1),       # strip kernel: 3->192 (3 cout groups -> 4 waves, one idle)
     (2, 64, 37, 45, 1, 3, 1, 1, 0, 0.0, 1),        # few-cout kernel: PostProcess 64->1 with residual, 4 chunks
     (1, 16, 33, 70, 1, 3, 1, 1, 2, 0.1, 2),        # few-cout kernel: 16->1, leaky, two residuals
+    (1, 192, 37, 53, 768, 1, 1, 0, 2, 0.1, 0),     # 1x1 GEMM kernel: MV-codec 192->768, ragged pixel count, 3 k-chunks
+    (1, 768, 18, 31, 192, 1, 1, 0, 0, 0.0, 1),     # 1x1 GEMM kernel: 768->192 with residual, 12 k-chunks
+    (2, 64, 130, 129, 256, 1, 1, 0, 1, 0.0, 0),    # 1x1 GEMM kernel: 64-pixel workgroups (>= 32768 px), one k-chunk
+    (1, 80, 20, 36, 40, 1, 1, 0, 0, 0.0, 2),       # 1x1 GEMM kernel: 5 channel blocks (odd), cout not a multiple of 16
+    (1, 48, 9, 7, 24, 1, 1, 0, 3, 0.0, 0),         # 1x1 GEMM kernel: fewer pixels than one workgroup tile, tanh
 ]
 
 

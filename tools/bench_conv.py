@@ -36,7 +36,10 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
     ("lstm 32->32 576x960", 1, 576, 960, 32, 32, 3, 1, 1),
 ] + [("nscan %dx576x960" % n, n, 576, 960, 112, 112, 3, 1, 1) for n in (2, 3, 4, 6, 8, 12, 16)] \
-  + [("nscan64 %dx1152x1920" % n, n, 1152, 1920, 64, 64, 3, 1, 1) for n in (2, 4, 8)]
+  + [("nscan64 %dx1152x1920" % n, n, 1152, 1920, 64, 64, 3, 1, 1) for n in (2, 4, 8)] \
+  + [("k1 %d->%d %dx%d" % (ci, co, h, w), 1, h, w, ci, co, 1, 1, 0) for ci, co, h, w in
+     ((64, 256, 576, 960), (256, 64, 576, 960), (64, 64, 576, 960), (192, 768, 72, 120), (768, 192, 72, 120),
+      (192, 192, 72, 120), (192, 192, 36, 60))]
 
 
 def main():
