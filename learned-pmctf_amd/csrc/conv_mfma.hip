@@ -676,6 +676,153 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 specialisation of the pipelined 4x16-tile variant (mid-size planes and the remainder rows of the big
+// launches): same treatment as conv3x3s1_wave_kernel — unrolled taps, alternating weight-fragment sets, LDS addresses
+// = one register + immediates, staging offsets and bounds computed once — with the workgroup-shared, double-buffered
+// 6x18 patch and one barrier per 16-channel chunk of conv_mfma_pipe_kernel<MT,1,1,.>.  A wave owns one tile row.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
+    constexpr int LH = 6, LW = 18, MAXP = 2;
+    constexpr int BUFSZ = LH * LW * CP;
+    constexpr int E = LH * LW * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mtile0 = blockIdx.z * MT;
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = a.oy_base + ty * 4, ox0 = tx * 16;
+    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
+
+    f32x4 acc[MT];
+    {
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = *(const f32x4 *)(bp + mt * 16);
+    }
+    bool ok[MAXP];
+    unsigned goff[MAXP];
+    f32x4 pre[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = tid + 256 * j;
+        const int pix = e >> 2, part = e & 3;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        ok[j] = e < E && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[j] = ok[j] ? (unsigned)(((gy * a.W + gx) * a.Cin + part * 4) * 4) : 0u;
+        pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char *xn = (const char *)(a.x + (size_t)n * a.H * a.W * a.Cin);
+    auto fetch = [&](int cb) {
+        const char *base = xn + cb * (CB * 4);
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+            if (ok[j]) pre[j] = *(const f32x4 *)(base + goff[j]);
+    };
+    float *sdst = lds + (tid >> 2) * CP + (tid & 3) * 4;
+    auto stash = [&](int buf) {
+        float *d0 = sdst + buf * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            if (256 * j + 255 < E || tid + 256 * j < E) {
+                float2 *dst = (float2 *)(d0 + j * 64 * CP);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * 9 * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
+    const long wsteps = (long)a.ncb * 9;
+    f32x4 wf[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wf[0][mt] = *(const f32x4 *)(wq + mt * 256);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    long wstep = 0;
+    const float *bl = lds + (wave * LW + (lane & 15)) * CP + (lane >> 4);
+    float b0, b1;
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        const float *cur = bl + (cb & 1) * BUFSZ;
+        const bool more = cb + 1 < a.ncb;
+        if (more) fetch(cb + 1);
+        b0 = cur[0];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * LW + (t % 3)) * CP;
+            const int tnext = (((t + 1) / 3) * LW + ((t + 1) % 3)) * CP;
+            ++wstep;
+            {
+                const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) wf[(t + 1) & 1][mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
+            }
+            b1 = cur[toff + 4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0, acc[mt], 0, 0, 0);
+            b0 = cur[toff + 8];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][1], b1, acc[mt], 0, 0, 0);
+            b1 = cur[toff + 12];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][2], b0, acc[mt], 0, 0, 0);
+            if (t < 8) b0 = cur[tnext];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][3], b1, acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
+        if (more) stash((cb + 1) & 1);
+        __syncthreads();
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+    {
+        const int oy = oy0 + wave, ox = ox0 + (lane & 15);
+        if (oy < a.oy_end && ox < a.Wo) {
+            const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
+                if (co >= a.Cout) continue;
+                f32x4 v = acc[mt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+                if (vec) {
+                    if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                    if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                    *(f32x4 *)(a.y + pbase + co) = v;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (co + i < a.Cout) {
+                            float sv = v[i];
+                            if (a.res1) sv = sv + a.res1[pbase + co + i];
+                            if (a.res2) sv = sv + a.res2[pbase + co + i];
+                            a.y[pbase + co + i] = sv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Resident-patch variant for small planes (same arithmetic, same sum order): the workgroup stages the input patch of
 // its 4x16 tile for ALL input channels at once (one global-load latency instead of one per 16-channel chunk, a single
 // barrier), then every wave runs its 16 pixels x MT cout tiles straight through.  Small planes are latency-bound in
@@ -1112,7 +1259,7 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     if (smem > 160 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
     if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
-        if ((MT >= 4 || (MT == 1 && knob("WAVE_SMALL") != 0)) && wave_eligible(a)) {
+        if ((MT >= 4 || (MT == 1 && knob("WAVE_SMALL") != 0 && a.KH == 3 && a.KW == 3 && a.S == 1)) && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
             const bool k33 = a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
@@ -1143,6 +1290,13 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         // filters; the single-buffer variant keeps 3 waves/SIMD for MT<=4 and wins on 3x3/7x7 there.
         const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1);
         if (!v1_only && prefer_v2 && (a.Cin % CB) == 0 && 2 * smem <= 80 * 1024 && slots <= 9) {
+            if constexpr (NT == 1 && TW16 == 1) {
+                if (a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
+                    (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+                    PM_LAUNCH((conv3x3s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
+                    return pm_launch_status();
+                }
+            }
             static std::once_flag once_p6, once_p9;
             if (slots <= 6) {
                 allow_big_lds(conv_mfma_pipe_kernel<MT, NT, TW16, 6>, once_p6);
