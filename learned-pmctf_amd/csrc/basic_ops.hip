@@ -2,6 +2,7 @@
 // coalesced NHWC / planar accesses).  Each kernel restates one torch functional op of
 // the reference in PM-F32 arithmetic (same operation order as oracle/c/pm_ops.c).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "pm_device_math.h"
 #include "launch.h"
@@ -280,6 +281,94 @@ __global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__re
     }
 }
 
+// The same convolution with the input patch of an 8x32 pixel tile staged in LDS, 16 channels at a time (the spec's chunk):
+// the kernel above pulls K*K 64-byte runs per pixel through L1 (576 B for 64 B of HBM traffic at 3x3) and is bound
+// there; here every input value is read once from global memory and K*K times from LDS (pixel stride 20 words: eight
+// lanes' 16-byte reads cover the 32 banks exactly).  The global loads of a chunk are all issued before the first LDS
+// store, and the next chunk's while the current one is multiplied.  Thread = output pixel, weights wave-uniform scalars,
+// identical fmaf chain: chunk, ky, kx, ci ascending, zeros outside the image multiplied in like any other value.
+template <int K, int CIN, int CO>
+__global__ __launch_bounds__(256) void conv_fewcout_lds_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, const float *res1,
+                                                               const float *res2, float *y, int H, int W, int tiles_x,
+                                                               int tiles_y, int act, float slope) {
+    constexpr int P = K / 2, TH = 8, TW = 32, PH = TH + K - 1, PW = TW + K - 1, PS = 20;
+    constexpr int E = PH * PW * 4, SLOTS = (E + 255) / 256, NCH = CIN / 16;
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int r = tid >> 5, c = tid & 31;
+    const float *img = x + (long)n * H * W * CIN;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = bias ? bias[co] : 0.0f;
+    // staging slots e = tid + 256*j: pixel e >> 2 of the patch, channel quad e & 3
+    int goff[SLOTS];                                     // element offset inside the image, -1 = outside
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int e = tid + 256 * j;
+        const int px = e >> 2, q = e & 3;
+        const int ly = px / PW, lx = px - ly * PW;
+        const int gy = oy0 - P + ly, gx = ox0 - P + lx;
+        goff[j] = (e < E && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * CIN + q * 4 : -1;
+    }
+    float4 pre[SLOTS];
+    auto fetch = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (goff[j] >= 0) pre[j] = *(const float4 *)(img + goff[j] + cb * 16);
+        }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int cb = 0; cb < NCH; ++cb) {
+        if (cb) __syncthreads();                         // previous chunk consumed
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int e = tid + 256 * j;
+            if (e < E) *(float4 *)(patch + (e >> 2) * PS + (e & 3) * 4) = pre[j];
+        }
+        __syncthreads();
+        if (cb + 1 < NCH) fetch(cb + 1);
+        const float *wc = w + cb * 16 * K * K;
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const float *row = patch + ((r + ky) * PW + c) * PS;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *(const float4 *)(row + kx * PS + q * 4);
+                    v[q * 4] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+                }
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co)
+                        acc[co] = __builtin_fmaf(v[ci], wc[((co * CIN + ci) * K + ky) * K + kx], acc[co]);
+            }
+        }
+    }
+    const int oy = oy0 + r, ox = ox0 + c;
+    if (oy < H && ox < W) {
+        const long idx = ((long)n * H + oy) * W + ox;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float v = pm::apply_act(acc[co], act, slope);
+            const long o = idx * CO + co;
+            if (res1) v = v + res1[o];
+            if (res2) v = v + res2[o];
+            y[o] = v;
+        }
+    }
+}
+
 // depthwise KxK, stride 1, pad K/2; NHWC, channel fastest
 __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                               float *y, int N, int H, int W, int C, int K) {
@@ -547,7 +636,16 @@ extern "C" int pmctf_conv2d_fewcout_f32(const float *x, const float *w, const fl
     unsigned g = nblocks((long)N * H * W);
     if (g > 16384) g = 16384;
     hipStream_t st = (hipStream_t)stream;
+    static const bool use_lds = [] { const char *e = getenv("PMCTF_FEWCOUT_LDS"); return !e || atoi(e) != 0; }();
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    const long tiles = (long)N * tiles_x * tiles_y;
 #define PM_FC(K_, CI_, CO_)                                                                                           \
+    if (use_lds && tiles <= 0x7fffffffL && (long)H * W * CI_ < 0x7fffffffL) {                                         \
+        const size_t smem = (size_t)(8 + K_ - 1) * (32 + K_ - 1) * 20 * sizeof(float);                                \
+        PM_LAUNCH((conv_fewcout_lds_kernel<K_, CI_, CO_>), dim3((unsigned)tiles), dim3(256), smem, st, x, w, bias,     \
+                  res1, res2, y, H, W, tiles_x, tiles_y, act, slope);                                                 \
+        return launch_ok();                                                                                           \
+    }                                                                                                                 \
     PM_LAUNCH((conv_fewcout_pix_kernel<K_, CI_, CO_>), dim3(g), dim3(256), 0, st, x, w, bias, res1, res2, y, N, H, W,   \
               act, slope);                                                                                            \
     return launch_ok();

@@ -6,6 +6,7 @@ Feature maps are NHWC float32 tensors of shape (N, H, W, C); single-channel plan
 (N, 1, H, W) alias the same memory.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -37,6 +38,10 @@ def _dev(x):
     return x.device
 
 
+# filters larger than this go to the matrix-core kernel even with one or two couts (see Conv2d.__init__)
+FEWCOUT_MAX_K = int(os.environ.get("PMCTF_FEWCOUT_MAX_K", "7"))
+
+
 class Conv2d:
     """A packed nn.Conv2d (groups=1): weights re-laid out once for the MFMA kernel
     (Cin % 4 == 0) or kept OIHW for the small-Cin vector kernel."""
@@ -53,7 +58,8 @@ class Conv2d:
         L = _lib.hip()
         # one or two couts: vector-ALU kernel on plain OIHW weights (a matrix-core tile would be 15/16 empty)
         self.few = (not self.small and self.stride == 1 and self.KH == self.KW and self.pad == (self.KH // 2,) * 2
-                    and bool(L.pmctf_conv2d_fewcout_supported(self.Cin, self.Cout, self.KH)))
+                    and bool(L.pmctf_conv2d_fewcout_supported(self.Cin, self.Cout, self.KH))
+                    and self.KH <= FEWCOUT_MAX_K)
         if self.small or self.few:
             self.w = w.to(device)
             self.b = None if b is None else b.to(device)
