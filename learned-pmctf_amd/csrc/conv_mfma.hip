@@ -823,6 +823,181 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// 7x7 / stride 1 on 8x32 tiles (SpyNet's 32->64, 64->32, 32->16 layers on the large pyramid levels): the pipelined
+// workgroup-shared variant with the treatment of the 3x3 kernels above — the seven taps of a filter row unrolled with
+// alternating weight-fragment sets (one copy per filter row), LDS addresses = one register per filter row + immediates,
+// staging offsets and bounds computed once per tile, the next chunk's patch fetched into registers while the current
+// one is multiplied (the generic single-buffer kernel waits for every chunk's loads and spends a quarter of its issue
+// slots on address arithmetic when MT = 1).  Same sums, same order.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
+    constexpr int K = 7, NT = 4, TH = 8, TW = 32, LH = TH + K - 1, LW = TW + K - 1;
+    constexpr int BUFSZ = LH * LW * CP;
+    constexpr int E = LH * LW * 4, MAXP = (E + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n = blockIdx.y;
+    const int mtile0 = blockIdx.z * MT;
+    const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = a.oy_base + ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
+
+    f32x4 acc[MT][NT];
+    {
+        const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+        }
+    }
+    bool ok[MAXP];
+    unsigned goff[MAXP];
+    f32x4 pre[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = tid + 256 * j;
+        const int pix = e >> 2, part = e & 3;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        ok[j] = e < E && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[j] = ok[j] ? (unsigned)(((gy * a.W + gx) * a.Cin + part * 4) * 4) : 0u;
+        pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char *xn = (const char *)(a.x + (size_t)n * a.H * a.W * a.Cin);
+    auto fetch = [&](int cb) {
+        const char *base = xn + cb * (CB * 4);
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+            if (ok[j]) pre[j] = *(const f32x4 *)(base + goff[j]);
+    };
+    float *sdst = lds + (tid >> 2) * CP + (tid & 3) * 4;
+    auto stash = [&](int buf) {
+        float *d0 = sdst + buf * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            if (256 * j + 255 < E || tid + 256 * j < E) {
+                float2 *dst = (float2 *)(d0 + j * 64 * CP);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    const int wstride = a.mtp * 256;
+    const float *wq = a.wp + (size_t)mb * a.ncb * (K * K) * wstride + mtin * 256 + lane * 4;   // walks [cb][tap]
+    const long wsteps = (long)a.ncb * (K * K);
+    f32x4 wf[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wf[0][mt] = *(const f32x4 *)(wq + mt * 256);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    long wstep = 0;
+    // segment nt of this wave: row 2*wave + (nt >> 1), columns 16*(nt & 1) ..
+    const float *bl = lds + ((2 * wave) * LW + (lane & 15)) * CP + (lane >> 4);
+    constexpr int SEG[4] = {0, 16 * CP, LW * CP, LW * CP + 16 * CP};
+    float b0[NT], b1[NT];
+    for (int cb = 0; cb < a.ncb; ++cb) {
+        const float *cur = bl + (cb & 1) * BUFSZ;
+        const bool more = cb + 1 < a.ncb;
+        if (more) fetch(cb + 1);
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const float *row = cur + ky * (LW * CP);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = row[SEG[nt]];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int toff = kx * CP;
+                ++wstep;
+                {
+                    const long wn = wstep < wsteps ? wstep : wsteps - 1;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        wf[(kx + 1) & 1][mt] = *(const f32x4 *)(wq + wn * wstride + mt * 256);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b1[nt] = row[SEG[nt] + toff + 4];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kx & 1][mt][0], b0[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b0[nt] = row[SEG[nt] + toff + 8];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kx & 1][mt][1], b1[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b1[nt] = row[SEG[nt] + toff + 12];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kx & 1][mt][2], b0[nt], acc[mt][nt], 0, 0, 0);
+                if (kx + 1 < K) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b0[nt] = row[SEG[nt] + toff + CP];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kx & 1][mt][3], b1[nt], acc[mt][nt], 0, 0, 0);
+            }
+            // seven taps: the next row's first fragments arrived in set 1
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
+        }
+        if (more) stash((cb + 1) & 1);
+        __syncthreads();
+    }
+
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + 2 * wave + (nt >> 1), ox = ox0 + 16 * (nt & 1) + (lane & 15);
+        if (oy >= a.oy_end || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
+            if (co >= a.Cout) continue;
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+            if (vec) {
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
+                *(f32x4 *)(a.y + pbase + co) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (co + i < a.Cout) {
+                        float sv = v[i];
+                        if (a.res1) sv = sv + a.res1[pbase + co + i];
+                        if (a.res2) sv = sv + a.res2[pbase + co + i];
+                        a.y[pbase + co + i] = sv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Resident-patch variant for small planes (same arithmetic, same sum order): the workgroup stages the input patch of
 // its 4x16 tile for ALL input channels at once (one global-load latency instead of one per 16-channel chunk, a single
 // barrier), then every wave runs its 16 pixels x MT cout tiles straight through.  Small planes are latency-bound in
@@ -1208,7 +1383,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1280,6 +1455,15 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
             static std::once_flag once_w;
             allow_big_lds(conv_mfma_wave_kernel<MT, 7>, once_w);
             PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
+            return pm_launch_status();
+        }
+    }
+    if constexpr (NT == 4 && TW16 == 2 && MT <= 4) {
+        if (a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 && knob("K77") != 0 &&
+            (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+            static std::once_flag once_7;
+            allow_big_lds(conv7x7s1_pipe_kernel<MT>, once_7);
+            PM_LAUNCH((conv7x7s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
             return pm_launch_status();
         }
     }

@@ -153,7 +153,8 @@ def test_resample_bitexact(cuda):
 
 @pytest.mark.parametrize("shape", [(1, 112, 44, 72, 112, 3, 1), (2, 64, 70, 100, 64, 3, 1), (1, 112, 264, 520, 112, 3, 1),
                                    (1, 16, 140, 150, 16, 3, 1),
-                                   (1, 32, 48, 80, 64, 7, 1), (1, 64, 64, 96, 128, 3, 2)])
+                                   (1, 32, 48, 80, 64, 7, 1), (1, 64, 45, 70, 32, 7, 1), (2, 32, 37, 50, 16, 7, 1),
+                                   (1, 64, 64, 96, 128, 3, 2), (1, 192, 20, 36, 256, 1, 1)])
 def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     """Every way of cutting a convolution into workgroups (cout-tile split, row split, tile size, kernel variant)
     gives the same bits: pmctf_conv2d_set_option only moves work around."""
@@ -168,12 +169,17 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2))
     xd = nhwc(x)
     L = lib.hip()
-    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1, "C16": 1, "C16_WGS": 512}
+    defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1,
+                "C16": 1, "C16_WGS": 512, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1}
     settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
                 {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}, {"MSPLIT_NT": 2, "MSPLIT_PX": 1 << 40},
-                {"MSPLIT_NT": 4, "MSPLIT_PX": 1 << 40}, {"C16": 0}, {"C16_WGS": 3}]
+                {"MSPLIT_NT": 4, "MSPLIT_PX": 1 << 40}, {"C16": 0}, {"C16_WGS": 3},
+                # the shape-specialised kernels against the generic ones
+                {"K33": 0, "NT": 4, "MSPLIT_PX": 0}, {"K33": 0, "NT": 1, "MSPLIT_PX": 0}, {"K77": 0, "NT": 4, "MSPLIT_PX": 0},
+                {"K11": 0}, {"WAVE_SMALL": 0, "MSPLIT_PX": 1 << 40}, {"WAVE_SMALL": 1, "MSPLIT_PX": 1 << 40},
+                {"NBUF1": 0, "NT": 4, "MSPLIT_PX": 0}]
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():

@@ -31,6 +31,10 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("post64 luma 1152x1920", 1, 1152, 1920, 64, 64, 3, 1, 1),
     ("spynet 32->64 7x7 1152x1920", 1, 1152, 1920, 32, 64, 7, 1, 3),
     ("spynet 8->32 7x7 1152x1920", 1, 1152, 1920, 8, 32, 7, 1, 3),
+    ("spynet 64->32 7x7 1152x1920", 1, 1152, 1920, 64, 32, 7, 1, 3),
+    ("spynet 32->16 7x7 1152x1920", 1, 1152, 1920, 32, 16, 7, 1, 3),
+    ("spynet 32->64 7x7 576x960", 1, 576, 960, 32, 64, 7, 1, 3),
+    ("spynet 32->16 7x7 576x960", 1, 576, 960, 32, 16, 7, 1, 3),
     ("pu 16->16 3x3 1152x1920", 1, 1152, 1920, 16, 16, 3, 1, 1),
     ("pu 16->1 3x3 1152x1920", 1, 1152, 1920, 16, 1, 3, 1, 1),
     ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
