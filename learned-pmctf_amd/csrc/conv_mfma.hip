@@ -1153,22 +1153,29 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) boff[nt] = (nt * LW + (lane & 15)) * CP + (lane >> 4);
 
+    // staging slots e = lane + 64*j: patch pixel (ly, lx) and byte offset relative to the patch origin are the same for
+    // every tile; per tile only the (wave-uniform, scalar) origin moves and two bounds compares per slot remain
     f32x4 pre[MAXP];
+    int sly[MAXP], slx[MAXP], rel[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = lane + 64 * j;
+        const int pix = e >> 2, part = e & 3;
+        sly[j] = pix / LW;
+        slx[j] = pix - sly[j] * LW;
+        rel[j] = ((sly[j] * a.W + slx[j]) * 16 + part * 4) * 4;
+        if (e >= E) sly[j] = -(1 << 20);                   // never inside the image
+    }
     auto fetch = [&](int tile) {
         const int n = tile / per_img, r = tile - n * per_img;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int iy0 = ty * 4 - 1, ix0 = tx * 16 - 1;
+        const char *base = (const char *)a.x + (((long)n * a.H + iy0) * a.W + ix0) * 64;     // scalar; may lie before row 0
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
-            const int e = lane + 64 * j;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < E) {
-                const int pix = e >> 2, part = e & 3;
-                const int ly = pix / LW, lx = pix - ly * LW;
-                const int gy = iy0 + ly, gx = ix0 + lx;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *(const f32x4 *)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * 16 + part * 4);
-            }
+            if ((unsigned)(iy0 + sly[j]) < (unsigned)a.H && (unsigned)(ix0 + slx[j]) < (unsigned)a.W)
+                v = *(const f32x4 *)(base + rel[j]);
             pre[j] = v;
         }
     };
