@@ -680,11 +680,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
 // launches): same treatment as conv3x3s1_wave_kernel — unrolled taps, alternating weight-fragment sets, LDS addresses
 // = one register + immediates, staging offsets and bounds computed once — with the workgroup-shared, double-buffered
 // 6x18 patch and one barrier per 16-channel chunk of conv_mfma_pipe_kernel<MT,1,1,.>.  A wave owns one tile row.
-template <int MT>
+// S = 2: the stride-2 form of the quarter-resolution context convolutions (9x33 patch).
+template <int MT, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
-    constexpr int LH = 6, LW = 18, MAXP = 2;
+    constexpr int LH = 3 * S + 3, LW = 15 * S + 3;
     constexpr int BUFSZ = LH * LW * CP;
-    constexpr int E = LH * LW * 4;
+    constexpr int E = LH * LW * 4, MAXP = (E + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
     const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = a.oy_base + ty * 4, ox0 = tx * 16;
-    const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
+    const int iy0 = oy0 * S - a.pad_h, ix0 = ox0 * S - a.pad_w;
 
     f32x4 acc[MT];
     {
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
     stash(0);
     __syncthreads();
     long wstep = 0;
-    const float *bl = lds + (wave * LW + (lane & 15)) * CP + (lane >> 4);
+    const float *bl = lds + (wave * S * LW + (lane & 15) * S) * CP + (lane >> 4);
     float b0, b1;
     for (int cb = 0; cb < a.ncb; ++cb) {
         const float *cur = bl + (cb & 1) * BUFSZ;
@@ -1485,6 +1486,11 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
                 if (a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
                     (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
                     PM_LAUNCH((conv3x3s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
+                    return pm_launch_status();
+                }
+                if (a.KH == 3 && a.KW == 3 && a.S == 2 && knob("K33") != 0 &&
+                    (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+                    PM_LAUNCH((conv3x3s1_pipe_kernel<MT, 2>), grid, dim3(256), 2 * smem, st, b);
                     return pm_launch_status();
                 }
             }
