@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
     const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = a.oy_base + ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
+    if (oy0 >= a.oy_end || ox0 >= a.Wo) return;          // this wave's 4x16 tile lies outside the plane (no barriers here)
     const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
     float *wlds = lds + wave * NBUF * BUFSZ;
 
@@ -1442,7 +1443,7 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     if (smem > 160 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
     if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
-        if ((MT >= 4 || (MT == 1 && knob("WAVE_SMALL") != 0 && a.KH == 3 && a.KW == 3 && a.S == 1)) && wave_eligible(a)) {
+        if ((MT >= 4 || ((MT == 2 || (MT == 1 && knob("WAVE_SMALL") != 0)) && a.KH == 3 && a.KW == 3 && a.S == 1)) && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
             const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
             const bool k33 = a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
@@ -1567,13 +1568,17 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
             if (rc != PMCTF_EINVAL) return rc;
         }
         const long mnt = knob("MSPLIT_NT");
-        // 3x3 stride 1 whose planes fill 8x32 tiles to >= 90 %: the barrier-free wave-private kernel with one cout tile
+        // 3x3 stride 1 whose planes fill the waves' 4x16 tiles to >= 90 %: the barrier-free wave-private kernel with one cout tile
         // per workgroup (a wave owns a 4x16 tile and its own patch; 4x fewer, 4x longer wave tasks than the 4x16
         // workgroup tiles below and no barriers).  tools/bench_conv.py: 144x240 79 -> 103 TFLOP/s, 8x72x120 81 -> 107,
         // 2x72x120 67 -> 87; planes that fit the tiles badly (36x60: 18 % padding) stay on the fine tiles.
         if (knob("WAVE_SMALL") != 0 && mnt == 1 && a.KH == 3 && a.KW == 3 && a.S == 1 && wave_eligible(a)) {
-            const long padded = (long)((a.Ho + 7) / 8) * 8 * ((a.Wo + 31) / 32) * 32;
-            if (padded * 10 <= (long)a.Ho * a.Wo * 11) return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
+            const long hw = (long)a.Ho * a.Wo;
+            const long padded = (long)((a.Ho + 3) / 4) * 4 * ((a.Wo + 15) / 16) * 16;     // waves without a tile exit at once
+            const long padded_wg = (long)((a.Ho + 7) / 8) * 8 * ((a.Wo + 31) / 32) * 32;
+            const long tasks = (long)a.N * (padded / 64) * MTP * MB;                       // wave tasks for 1024 SIMDs
+            if (padded * 10 <= hw * 11 && (padded_wg * 10 <= hw * 11 || tasks >= 3500))
+                return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
         }
         if (mnt == 2) return launch<1, 2, 1>(a, MTP * MB, st, 0, a.Ho);
         if (mnt == 4 && a.S == 1) return launch<1, 4, 2>(a, MTP * MB, st, 0, a.Ho);
