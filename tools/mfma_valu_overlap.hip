@@ -1,3 +1,13 @@
+// Do f32 MFMA and vector-ALU instructions overlap on a gfx950 SIMD?  (They do not.)
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/mfma_valu_overlap.hip -o /tmp/mfma_valu_overlap && /tmp/mfma_valu_overlap
+// One workgroup of W waves; every wave runs 256 x CH v_mfma_f32_16x16x4_f32 (CH independent accumulator chains) with V
+// independent v_fma_f32 after each; reported: cycles (s_memtime) from the first wave's start to the last wave's end per
+// MFMA of one wave.  Measured on MI355X:
+//   chains 2, 0 VALU, 4 waves (1 per SIMD): 34.1      chains 2, 0 VALU, 8 waves (2 per SIMD): 65.6  (the pipe is full)
+//   chains 2, 4 VALU: 62.4   6 VALU: 72.4   8 VALU: 83.7   16 VALU: 119.5      (4 waves: + 5.3 cycles per VALU instruction)
+//   chains 2, 6 VALU, 8 waves: 110.7   16 VALU, 8 waves: 212.4                  (= 2 x (32 + 4.6 V): no overlap across waves)
+// i.e. time = MFMA cycles + VALU cycles, within a wave and between the waves of a SIMD.  A single dependent chain issues
+// a 16x16x4 f32 MFMA every 35 cycles (32 = 8 passes), so one chain nearly saturates the pipe.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,4 +1,9 @@
-// Per-phase cycle counts of the fused PredictUpdate kernel (debug tool; build: see tools/pu_prof.sh).
+// Per-phase cycle counts of the fused PredictUpdate kernel (debug tool, not part of the product library).
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 tools/pu_prof.hip -o learned-pmctf_amd/lib/pu_prof
+//   learned-pmctf_amd/lib/pu_prof <planes> [extra LDS bytes: 30000 forces one workgroup per CU]
+// Measured on MI355X (1152x1920 plane): P0 5.5k, P1 (tanh(conv1), vector ALU) 28.8k, P2 (MFMA + tanh) 19.9k, P3 (MFMA + c1)
+// 12.7k, P4 (16->1) 5.9k cycles per workgroup with two workgroups per CU; one per CU: P1 15.6k, the MFMA phases
+// unchanged - vector and matrix work of the two workgroups add up on a SIMD instead of overlapping.
 #define PMCTF_PU_PROFILE 1
 #include "../learned-pmctf_amd/csrc/pu_fused.hip"
 #include <cstdio>
