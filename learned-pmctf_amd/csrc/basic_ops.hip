@@ -449,6 +449,72 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float *__restr
     }
 }
 
+// The same with a vertical walk: a thread owns 4 channels of a PX-wide column of RY output rows and keeps a rolling window
+// of three input rows in registers, so every input row is loaded once per thread instead of three times ((RY+2)/RY x
+// (PX+2)/PX = 1.9x read amplification through L1 instead of 4.5x).  Same fmaf chain per output: acc = bias; ky, kx.
+template <int PX, int RY>
+__global__ __launch_bounds__(256) void dwconv3_column_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, float *y, int N, int H, int W,
+                                                             int C) {
+    const int C4 = C >> 2;
+    const int strips = (W + PX - 1) / PX, bands = (H + RY - 1) / RY;
+    const long total = (long)N * bands * strips * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long r = idx / C4;
+        const int sx = (int)(r % strips) * PX;
+        r /= strips;
+        const int oy0 = (int)(r % bands) * RY;
+        const long n = r / bands;
+        float4 wr[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            wr[t] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+        const float4 b = bias ? *(const float4 *)(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *img = x + (n * H * W) * C + c;
+        auto load_row = [&](int iy, float4 *in) {
+            const bool rowok = iy >= 0 && iy < H;
+            const float *row = img + (long)(rowok ? iy : 0) * W * C;
+#pragma unroll
+            for (int j = 0; j < PX + 2; ++j) {
+                const int ix = sx + j - 1;
+                in[j] = (rowok && ix >= 0 && ix < W) ? *(const float4 *)(row + (long)ix * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        float4 win[3][PX + 2];
+        load_row(oy0 - 1, win[0]);
+        load_row(oy0, win[1]);
+#pragma unroll
+        for (int ry = 0; ry < RY; ++ry) {
+            const int oy = oy0 + ry;
+            if (oy >= H) break;
+            load_row(oy + 1, win[(ry + 2) % 3]);
+            float4 acc[PX];
+#pragma unroll
+            for (int j = 0; j < PX; ++j) acc[j] = b;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float4 *in = win[(ry + ky) % 3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 wt = wr[ky * 3 + kx];
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        acc[j].x = __builtin_fmaf(in[j + kx].x, wt.x, acc[j].x);
+                        acc[j].y = __builtin_fmaf(in[j + kx].y, wt.y, acc[j].y);
+                        acc[j].z = __builtin_fmaf(in[j + kx].z, wt.z, acc[j].z);
+                        acc[j].w = __builtin_fmaf(in[j + kx].w, wt.w, acc[j].w);
+                    }
+                }
+            }
+            float *o = y + ((n * H + oy) * W + sx) * C + c;
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                if (sx + j < W) *(float4 *)(o + (long)j * C) = acc[j];
+        }
+    }
+}
+
 // flow warp: one thread per output pixel, loop over planes
 __global__ void flow_warp_kernel(const float *__restrict__ im, const float *__restrict__ flow,
                                  const float *__restrict__ lin_x, const float *__restrict__ lin_y, float *out,
@@ -659,6 +725,14 @@ extern "C" int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const flo
                                        int W, int C, int K, void *stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || !(K & 1)) return PMCTF_EINVAL;
     if (K == 3 && (C & 3) == 0) {
+        static const int column = [] { const char *e = getenv("PMCTF_DWCONV_COLUMN"); return e ? atoi(e) : 1; }();
+        const long threads_col = (long)N * ((H + 7) / 8) * ((W + 3) / 4) * (C / 4);
+        if (column && threads_col >= 256L * 1024) {          // enough columns to fill the chip four times over
+            unsigned gc = nblocks(threads_col);
+            if (gc > 16384) gc = 16384;
+            PM_LAUNCH((dwconv3_column_kernel<4, 8>), dim3(gc), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C);
+            return launch_ok();
+        }
         unsigned g4 = nblocks((long)N * H * ((W + 3) / 4) * (C / 4));
         if (g4 > 16384) g4 = 16384;
         PM_LAUNCH(dwconv3_strip_kernel<4>, dim3(g4), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, C);

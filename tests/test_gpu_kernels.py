@@ -104,7 +104,8 @@ def test_conv2d_denormals_and_specials(cuda):
     assert_same(nchw(y), ref, "denormal conv")
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 37, 51), (1, 112, 20, 36), (1, 6, 19, 23), (1, 192, 3, 2)])
+@pytest.mark.parametrize("shape", [(2, 64, 37, 51), (1, 112, 20, 36), (1, 6, 19, 23), (1, 192, 3, 2),
+                                   (2, 128, 331, 421)])      # the last one is large enough for the column-walking kernel
 def test_dwconv_bitexact(cuda, shape):
     from pmctf_oracle import clib
     from pMCTF.hip import ops
