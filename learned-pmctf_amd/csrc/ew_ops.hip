@@ -117,6 +117,54 @@ __global__ void pixel_shuffle2_kernel(const float *__restrict__ x, float *y, int
     }
 }
 
+// C % 4 == 0 forms: a thread owns four channels of one INPUT pixel and writes the four output pixels it feeds with
+// 16-byte stores (the scalar kernels above spend their time on index arithmetic and 4-byte accesses).
+__global__ __launch_bounds__(256) void nearest_up2_vec4_kernel(const float *__restrict__ x, float *y, int N, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long total = (long)N * H * W * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        long r = idx / C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const long n = r / H;
+        const float4 v = *(const float4 *)(x + ((n * H + h) * W + w) * C + c);
+        float *o = y + ((n * 2 * H + 2 * h) * (2L * W) + 2 * w) * C + c;
+        *(float4 *)o = v;
+        *(float4 *)(o + C) = v;
+        *(float4 *)(o + 2L * W * C) = v;
+        *(float4 *)(o + 2L * W * C + C) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *__restrict__ x, float *y, int N, int H, int W, int C,
+                                                                  int act, float slope) {
+    const int C4 = C >> 2;
+    const long total = (long)N * H * W * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;                       // output channels c .. c+3 = input channels 4c .. 4c+15
+        long r = idx / C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const long n = r / H;
+        const float4 *p = (const float4 *)(x + ((n * H + h) * W + w) * (4L * C) + 4 * c);
+        float4 q[4];                                             // q[k] = input channels of output channel c+k: (i,j) = x,y,z,w
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = p[k];
+        float *o = y + ((n * 2 * H + 2 * h) * (2L * W) + 2 * w) * C + c;
+        const float4 o00 = make_float4(q[0].x, q[1].x, q[2].x, q[3].x), o01 = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
+        const float4 o10 = make_float4(q[0].z, q[1].z, q[2].z, q[3].z), o11 = make_float4(q[0].w, q[1].w, q[2].w, q[3].w);
+        auto a4 = [&](float4 v) {
+            return make_float4(pm::apply_act(v.x, act, slope), pm::apply_act(v.y, act, slope), pm::apply_act(v.z, act, slope),
+                               pm::apply_act(v.w, act, slope));
+        };
+        *(float4 *)o = a4(o00);
+        *(float4 *)(o + C) = a4(o01);
+        *(float4 *)(o + 2L * W * C) = a4(o10);
+        *(float4 *)(o + 2L * W * C + C) = a4(o11);
+    }
+}
+
 // ConvFFN3 gate (video/layers.py:163-167): out = leaky(x1, 0.1) + leaky(x2, 0.01), x = [x1 | x2] on channels
 __global__ void ffn3_mix_kernel(const float *__restrict__ x, float *y, long P, int C) {
     const long total = P * C;
@@ -303,6 +351,11 @@ extern "C" int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int
 
 extern "C" int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, void *stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
+    if ((C & 3) == 0) {
+        PM_LAUNCH(nearest_up2_vec4_kernel, dim3(grid_for((long)N * H * W * (C >> 2))), dim3(256), 0, (hipStream_t)stream, x,
+                  y, N, H, W, C);
+        return launch_ok();
+    }
     PM_LAUNCH(nearest_up2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream, x,
                        y, N, H, W, C);
     return launch_ok();
@@ -311,6 +364,11 @@ extern "C" int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H
 extern "C" int pmctf_pixel_shuffle2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, int act, float slope,
                                              void *stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return PMCTF_EINVAL;
+    if ((C & 3) == 0) {
+        PM_LAUNCH(pixel_shuffle2_vec4_kernel, dim3(grid_for((long)N * H * W * (C >> 2))), dim3(256), 0, (hipStream_t)stream,
+                  x, y, N, H, W, C, act, slope);
+        return launch_ok();
+    }
     PM_LAUNCH(pixel_shuffle2_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0, (hipStream_t)stream,
                        x, y, N, H, W, C, act, slope);
     return launch_ok();

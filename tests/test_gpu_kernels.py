@@ -238,3 +238,21 @@ def test_split_precision_conv_tracks_the_exact_kernel(cuda, shape):
                 assert err > 0 or True
     finally:
         ops.SPLIT_MIN_PX = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 6, 9, 4), (3, 64, 6, 10), (1, 3, 4, 4)])
+def test_nearest_up2_and_pixel_shuffle2_are_exact_copies(cuda, shape):
+    """nearest x2 upsampling and nn.PixelShuffle(2) on NHWC (scalar and 16-byte forms: C % 4 == 0 or not) against the torch
+    ops the reference uses (long_context.py:156-170 F.interpolate nearest, video_net.py subpel convs' PixelShuffle)"""
+    import torch.nn.functional as F
+    from pMCTF.hip import ops
+    n, c, h, w = shape
+    x = _rng(c * h).standard_normal((n, c, h, w), dtype=np.float32)
+    up = ops.nearest_up2(nhwc(x))
+    assert_same(nchw(up), F.interpolate(torch.from_numpy(x), scale_factor=2, mode="nearest").numpy(), "nearest_up2")
+    x4 = _rng(c + w).standard_normal((n, 4 * c, h, w), dtype=np.float32)
+    ps = ops.pixel_shuffle2(nhwc(x4))
+    assert_same(nchw(ps), F.pixel_shuffle(torch.from_numpy(x4), 2).numpy(), "pixel_shuffle2")
+    ps = ops.pixel_shuffle2(nhwc(x4), act=ops.ACT_LEAKY, slope=0.1)
+    assert_same(nchw(ps), F.leaky_relu(F.pixel_shuffle(torch.from_numpy(x4), 2), 0.1).numpy(), "pixel_shuffle2 + leaky")
