@@ -1561,7 +1561,11 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     // (1) small planes: too few 16-pixel segments to occupy 1024 SIMDs with whole M-blocks -> one cout tile per
     //     workgroup, MTP x more (and MTP x shorter) workgroups.  Same sums, same order.
     const long msplit_px = knob("MSPLIT_PX");
-    if (MTP >= 2 && px <= msplit_px) {
+    // stride-2 3x3 with 112 couts (the quarter-resolution context convolutions on the small DWT levels): the specialised
+    // pipelined kernel with all cout tiles per workgroup beats the cout-split generic one from 8 000 output pixels up
+    // (2x288x480 -> 2x144x240: 324 -> 177 us; tools/bench_conv.py "s2small")
+    const bool s2_whole = MTP >= 7 && a.S == 2 && a.KH == 3 && a.KW == 3 && (a.Cin % CB) == 0 && knob("K33") != 0 && px >= 8000;
+    if (MTP >= 2 && px <= msplit_px && !s2_whole) {
         if (knob("RES") == 1) {
             const int rc = launch_res<1>(a, MTP * MB, st);
             if (rc != PMCTF_EINVAL) return rc;

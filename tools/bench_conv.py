@@ -44,6 +44,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
   + [("nscan64 %dx1152x1920" % n, n, 1152, 1920, 64, 64, 3, 1, 1) for n in (2, 4, 8)] \
   + [("s2 112->112 3x3 %dx576x960" % n, n, 576, 960, 112, 112, 3, 2, 1) for n in (1, 4, 8)] \
   + [("s2 112->112 3x3 8x288x480", 8, 288, 480, 112, 112, 3, 2, 1)] \
+  + [("s2small 112->112 %dx%dx%d" % (n, h, w), n, h, w, 112, 112, 3, 2, 1) for n, h, w in
+     ((2, 288, 480), (8, 144, 240), (1, 288, 480), (4, 144, 240), (2, 144, 240), (8, 72, 120), (2, 72, 120))] \
   + [("few 16->2 7x7 1152x1920", 1, 1152, 1920, 16, 2, 7, 1, 3), ("few 16->2 7x7 576x960", 1, 576, 960, 16, 2, 7, 1, 3),
      ("few 16->1 3x3 8x1152x1920", 8, 1152, 1920, 16, 1, 3, 1, 1), ("few 64->1 3x3 8x1152x1920", 8, 1152, 1920, 64, 1, 3, 1, 1)] \
   + [("k1 %d->%d %dx%d" % (ci, co, h, w), 1, h, w, ci, co, 1, 1, 0) for ci, co, h, w in

@@ -37,3 +37,11 @@ if len(sys.argv) > 1:                       # per-launch durations of one signat
     d = [round(e0.elapsed_time(e1) * 1e3) for s, (e0, e1, fl) in zip(sigs, probe["events"])
          if s[0] == want and s[1] == int(sys.argv[5]) and s[2] == 3 and s[3] == 1]
     print("per-launch us:", d)
+if os.environ.get("CENSUS_SMALL"):
+    print("--- planes of at most 70 000 output pixels, by time ---")
+    small = [(s, a) for s, a in agg.items() if s[0][0] * (s[0][1] // s[3]) * (s[0][2] // s[3]) <= 70000]
+    st = sum(a[1] for _, a in small)
+    print(f"small-plane conv ms {st:.1f} of {tot:.1f}")
+    for s, a in sorted(small, key=lambda kv: -kv[1][1])[:40]:
+        (N, h, w, ci), co, k, stv = s
+        print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{stv}  n={a[0]:5d} {a[1]:8.1f} ms {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
