@@ -23,6 +23,9 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("batched 4x72x120", 4, 72, 120, 112, 112, 3, 1, 1),
     ("batched 16x36x60", 16, 36, 60, 112, 112, 3, 1, 1),
     ("batched 8x36x60", 8, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 4x36x60", 4, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 2x36x60", 2, 36, 60, 112, 112, 3, 1, 1),
+    ("batched 1x72x120", 1, 72, 120, 112, 112, 3, 1, 1),
     ("batched 4x144x240", 4, 144, 240, 112, 112, 3, 1, 1),
     ("batched 8x144x240", 8, 144, 240, 112, 112, 3, 1, 1),
     ("post64 chroma 2x576x960", 2, 576, 960, 64, 64, 3, 1, 1),
