@@ -45,3 +45,10 @@ if os.environ.get("CENSUS_SMALL"):
     for s, a in sorted(small, key=lambda kv: -kv[1][1])[:40]:
         (N, h, w, ci), co, k, stv = s
         print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{stv}  n={a[0]:5d} {a[1]:8.1f} ms {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
+if os.environ.get("CENSUS_K"):
+    kk = int(os.environ["CENSUS_K"])
+    rows = [(s, a) for s, a in agg.items() if s[2] == kk]
+    print(f"--- all {kk}x{kk} convolutions: {sum(a[1] for _, a in rows):.1f} ms ---")
+    for s, a in sorted(rows, key=lambda kv: -kv[1][1]):
+        (N, h, w, ci), co, k, stv = s
+        print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{stv}  n={a[0]:5d} {a[1]:8.1f} ms {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
