@@ -206,7 +206,7 @@ class HipEngine:
         self.motion_stream = torch.cuda.Stream(device=self.dev)
         self.lt_event, self.lt_tensor = None, None       # event behind the last batched luma lifting + that L_t tensor
         self.pu_fused = os.environ.get("PMCTF_PU_FUSED", "1") != "0"     # one launch per PredictUpdate + lifting step
-        self.pu_fused_max_px = int(os.environ.get("PMCTF_PU_FUSED_MAX_PX", "600000"))
+        self.pu_fused_max_px = int(os.environ.get("PMCTF_PU_FUSED_MAX_PX", "400000"))
         self.post_process_max_px = 8 * 1152 * 1920      # pixels per post-processing launch group (4.5 GB per 64-ch map)
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False

@@ -860,6 +860,7 @@ def test_fused_predict_update_equals_separate_launches(setup, shape):
     o = torch.from_numpy(rng.normal(0, 40, (n, 1, h, w)).astype(np.float32)).cuda()
     wt = "hp_coder.wavelet_transform.lift_h"
     got = {}
+    keep_max = eng.pu_fused_max_px
     eng.pu_fused_max_px = 1 << 40
     for fused in (True, False):
         eng.pu_fused = fused
@@ -868,7 +869,7 @@ def test_fused_predict_update_equals_separate_launches(setup, shape):
             r[pn + "+"] = eng.lift_step(wt, cn, pn, x, o, 1.0)
             r[pn + "-"] = eng.lift_step(wt, cn, pn, o, x, -1.0)
         got[fused] = r
-    eng.pu_fused, eng.pu_fused_max_px = True, 600000
+    eng.pu_fused, eng.pu_fused_max_px = True, keep_max
     for k in got[True]:
         assert_same(got[True][k], got[False][k], f"{shape} {k}")
     # and against the oracle directly
