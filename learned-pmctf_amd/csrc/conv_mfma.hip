@@ -834,9 +834,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
 // staging offsets and bounds computed once per tile, the next chunk's patch fetched into registers while the current
 // one is multiplied (the generic single-buffer kernel waits for every chunk's loads and spends a quarter of its issue
 // slots on address arithmetic when MT = 1).  Same sums, same order.
-template <int MT>
+// NT = 4: 8x32 tiles (a wave owns two rows); NT = 1: 4x16 tiles (a wave owns one 16-pixel row) for the small pyramid
+// levels, where the generic kernel waits for every tap's weights (105 us on a 36x60 plane that holds 3 us of work).
+template <int MT, int NT = 4>
 __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
-    constexpr int K = 7, NT = 4, TH = 8, TW = 32, LH = TH + K - 1, LW = TW + K - 1;
+    constexpr int K = 7, TH = NT == 4 ? 8 : 4, TW = NT == 4 ? 32 : 16, LH = TH + K - 1, LW = TW + K - 1;
     constexpr int BUFSZ = LH * LW * CP;
     constexpr int E = LH * LW * 4, MAXP = (E + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -903,8 +905,8 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
     stash(0);
     __syncthreads();
     long wstep = 0;
-    // segment nt of this wave: row 2*wave + (nt >> 1), columns 16*(nt & 1) ..
-    const float *bl = lds + ((2 * wave) * LW + (lane & 15)) * CP + (lane >> 4);
+    // NT = 4: segment nt of this wave = row 2*wave + (nt >> 1), columns 16*(nt & 1) ..; NT = 1: row wave
+    const float *bl = lds + (((NT == 4 ? 2 : 1) * wave) * LW + (lane & 15)) * CP + (lane >> 4);
     constexpr int SEG[4] = {0, 16 * CP, LW * CP, LW * CP + 16 * CP};
     float b0[NT], b1[NT];
     for (int cb = 0; cb < a.ncb; ++cb) {
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
     const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int oy = oy0 + 2 * wave + (nt >> 1), ox = ox0 + 16 * (nt & 1) + (lane & 15);
+        const int oy = oy0 + (NT == 4 ? 2 * wave + (nt >> 1) : wave), ox = ox0 + 16 * (nt & 1) + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 #pragma unroll
@@ -1470,12 +1472,12 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
             return pm_launch_status();
         }
     }
-    if constexpr (NT == 4 && TW16 == 2 && MT <= 4) {
+    if constexpr (((NT == 4 && TW16 == 2) || (NT == 1 && TW16 == 1)) && MT <= 4) {
         if (a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 && knob("K77") != 0 &&
             (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
             static std::once_flag once_7;
-            allow_big_lds(conv7x7s1_pipe_kernel<MT>, once_7);
-            PM_LAUNCH((conv7x7s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
+            allow_big_lds(conv7x7s1_pipe_kernel<MT, NT>, once_7);
+            PM_LAUNCH((conv7x7s1_pipe_kernel<MT, NT>), grid, dim3(256), 2 * smem, st, b);
             return pm_launch_status();
         }
     }
@@ -1613,10 +1615,14 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
             if (rounds < 1 || bands_a < 1) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
         }
         if (px >= 400000L || (MTP >= 4 && wave_eligible(a))) return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);
+        if (MTP == 1 && a.KH == 7 && a.KW == 7 && (a.Cin % CB) == 0 && knob("K77") != 0)
+            return launch<MTP, 4, 2>(a, MB, st, 0, a.Ho);      // 32->16 on the 288x480 level: 121 -> 89 us
     }
     // measured on MI355X (tools/bench_conv.py): the wide-cout kernels (MT>=7) prefer 4x16 tiles on everything
     // smaller (more workgroups -> less tail quantisation).
     if (MTP >= 7) return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
+    if (MTP <= 4 && px < 131072 && a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 && knob("K77") != 0)
+        return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);          // small SpyNet levels: 4x16 tiles of the 7x7 kernel
     if (px >= 64L * 64 * 4) return launch<MTP, 2, 1>(a, MB, st, 0, a.Ho);
     return launch<MTP, 1, 1>(a, MB, st, 0, a.Ho);
 }

@@ -38,6 +38,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("spynet 32->16 7x7 1152x1920", 1, 1152, 1920, 32, 16, 7, 1, 3),
     ("spynet 32->64 7x7 576x960", 1, 576, 960, 32, 64, 7, 1, 3),
     ("spynet 32->16 7x7 576x960", 1, 576, 960, 32, 16, 7, 1, 3),
+] + [("spysmall %d->%d 7x7 %dx%d" % (ci, co, h, w), 1, h, w, ci, co, 7, 1, 3) for h, w in ((288, 480), (144, 240), (72, 120), (36, 60))
+     for ci, co in ((32, 64), (64, 32), (32, 16))] + [
     ("pu 16->16 3x3 1152x1920", 1, 1152, 1920, 16, 16, 3, 1, 1),
     ("pu 16->1 3x3 1152x1920", 1, 1152, 1920, 16, 1, 3, 1, 1),
     ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
