@@ -1397,7 +1397,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1486,7 +1486,8 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         const int slots = (LH * LW * 4 + 255) / 256;
         // measured (tools/bench_conv.py): the pipelined variant wins for the wide-cout tiles (MT>=7) and for 1x1
         // filters; the single-buffer variant keeps 3 waves/SIMD for MT<=4 and wins on 3x3/7x7 there.
-        const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1);
+        const bool prefer_v2 = v2_only || MT >= 7 || (a.KH == 1 && a.KW == 1) ||
+                               (MT == 1 && NT == 1 && a.KH == 3 && a.KW == 3 && knob("K33_SMALL") != 0);
         if (!v1_only && prefer_v2 && (a.Cin % CB) == 0 && 2 * smem <= 80 * 1024 && slots <= 9) {
             if constexpr (NT == 1 && TW16 == 1) {
                 if (a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&

@@ -171,7 +171,7 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     xd = nhwc(x)
     L = lib.hip()
     defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1,
-                "C16": 1, "C16_WGS": 512, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1}
+                "C16": 1, "C16_WGS": 512, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1, "K33_SMALL": 1}
     settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
@@ -180,7 +180,8 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
                 # the shape-specialised kernels against the generic ones
                 {"K33": 0, "NT": 4, "MSPLIT_PX": 0}, {"K33": 0, "NT": 1, "MSPLIT_PX": 0}, {"K77": 0, "NT": 4, "MSPLIT_PX": 0},
                 {"K11": 0}, {"WAVE_SMALL": 0, "MSPLIT_PX": 1 << 40}, {"WAVE_SMALL": 1, "MSPLIT_PX": 1 << 40},
-                {"NBUF1": 0, "NT": 4, "MSPLIT_PX": 0}]
+                {"NBUF1": 0, "NT": 4, "MSPLIT_PX": 0}, {"K33_SMALL": 0, "MSPLIT_PX": 1 << 40, "WAVE_SMALL": 0},
+                {"K33_SMALL": 1, "MSPLIT_PX": 1 << 40, "WAVE_SMALL": 0}]
     try:
         for st in settings:
             for k, v in {**defaults, **st}.items():
