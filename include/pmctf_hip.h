@@ -53,7 +53,7 @@ int64_t pmctf_conv2d_packed_bias_size(int Cout);
  * (three workgroups per CU) for the wave-private kernel on layers of at most 64 couts, "K33" 0/1 the 3x3 stride-1
  * specialisations (wave-private and pipelined kernels, stride 1 and 2: no vector-ALU work in the tap loop), "K77" 0/1 the
  * 7x7 stride-1 pipelined kernel (8x32 and 4x16 tiles), "K33_SMALL" 0/1 the specialised 3x3 pipelined kernel with one cout
- * tile per workgroup on the cout-split planes the wave-private kernel does not take, "K11" 0/1 the flat GEMM kernel for 1x1 layers with >= 128 couts, "WAVE_SMALL" 0/1 the
+ * tile per workgroup on the cout-split planes the wave-private kernel does not take, "K11" 0/1 the flat GEMM kernel for 1x1 layers with at least "K11_MIN_TILES" (7) 16-cout tiles, "WAVE_SMALL" 0/1 the
  * wave-private kernel with one cout tile per workgroup on cout-split 3x3 planes that fill the waves' 4x16 tiles to >= 90 %.
  * Environment only: PMCTF_FEWCOUT_LDS=0 / PMCTF_DWCONV_COLUMN=0 select the older one/two-cout and depthwise kernels. */
 int pmctf_conv2d_set_option(const char *name, long value);

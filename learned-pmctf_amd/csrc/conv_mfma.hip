@@ -1397,7 +1397,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1645,7 +1645,7 @@ int launch_1x1(const ConvArgs &a, int tiles, hipStream_t st) {
     const bool big = P >= 32768;
     const long gx = (P + (big ? 63 : 31)) / (big ? 64 : 32);
     int mtw = 1;
-    for (int m = tiles >= 16 ? 4 : tiles / 4; m >= 1; --m)
+    for (int m = tiles >= 16 ? 4 : (tiles + 3) / 4; m >= 1; --m)
         if (gx * ((tiles + WAVES * m - 1) / (WAVES * m)) >= 512 || m == 1) { mtw = m; break; }
     if (big) {
         switch (mtw) {
@@ -1728,7 +1728,7 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
-        knob("K11") != 0 && MT * MB >= 8) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
+        knob("K11") != 0 && MT * MB >= knob("K11_MIN_TILES")) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
         a.mtp = MT;
         return launch_1x1(a, MT * MB, st);
     }

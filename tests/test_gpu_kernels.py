@@ -60,6 +60,7 @@ CONV_CASES = [
     (2, 64, 130, 129, 256, 1, 1, 0, 1, 0.0, 0),    # 1x1 GEMM kernel: 64-pixel workgroups (>= 32768 px), one k-chunk
     (1, 80, 20, 36, 40, 1, 1, 0, 0, 0.0, 2),       # 1x1 GEMM kernel: 5 channel blocks (odd), cout not a multiple of 16
     (1, 48, 9, 7, 24, 1, 1, 0, 3, 0.0, 0),         # 1x1 GEMM kernel: fewer pixels than one workgroup tile, tanh
+    (2, 112, 37, 41, 112, 1, 1, 0, 2, 0.2, 1),     # 1x1 GEMM kernel: 7 cout tiles on 4 waves (one wave with a single live tile)
 ]
 
 

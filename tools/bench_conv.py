@@ -43,6 +43,8 @@ SHAPES = [  # name, N, H, W, Cin, Cout, K, stride, pad
     ("pu 16->16 3x3 1152x1920", 1, 1152, 1920, 16, 16, 3, 1, 1),
     ("pu 16->1 3x3 1152x1920", 1, 1152, 1920, 16, 1, 3, 1, 1),
     ("1x1 112->112 576x960", 1, 576, 960, 112, 112, 1, 1, 0),
+    ("1x1 112->112 8x576x960", 8, 576, 960, 112, 112, 1, 1, 0),
+    ("1x1 112->112 8x144x240", 8, 144, 240, 112, 112, 1, 1, 0),
     ("lstm 32->32 576x960", 1, 576, 960, 32, 32, 3, 1, 1),
     ("lstm 32->32 8x576x960", 8, 576, 960, 32, 32, 3, 1, 1),
 ] + [("nscan %dx576x960" % n, n, 576, 960, 112, 112, 3, 1, 1) for n in (2, 3, 4, 6, 8, 12, 16)] \
