@@ -33,10 +33,16 @@ int pmctf_rans_encoder_reset(pmctf_rans_encoder *e);
 /* RansEncoder.encode_with_indexes(symbols, indexes, cdfs, cdfs_sizes, offsets)
  *                                                  py_rans.cpp:22-66 + rans.cpp:76-139
  * symbols/indexes: n int16 each; cdfs: [cdf_rows][cdf_cols] int32; cdf_sizes, offsets: [cdf_rows].
- * Inputs are consumed (mapped to start/range pairs) before the call returns. */
+ * The two int16 arrays are copied before the call returns (as the pybind wrapper copies its numpy arguments,
+ * py_rans.cpp:36-66) and coded at flush(); CDF rows are range-checked here. */
 int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t *symbols, const int16_t *indexes,
                                            int64_t n, const int32_t *cdfs, int cdf_rows, int cdf_cols,
                                            const int32_t *cdf_sizes, const int32_t *offsets);
+/* Not in the reference: borrow != 0 makes the following encode_with_indexes calls keep the caller's pointers instead
+ * of copying (the arrays must stay valid and unchanged until flush() has completed — for multi_thread encoders until
+ * stream_size / get_encoded_stream / write_file has returned).  Used by the product's writer threads, whose symbol
+ * buffers are pinned host memory owned by the job. */
+int pmctf_rans_encoder_set_borrow(pmctf_rans_encoder *e, int borrow);
 /* RansEncoder.flush()                                                 py_rans.cpp:68-72 + rans.cpp:141-168 */
 int pmctf_rans_encoder_flush(pmctf_rans_encoder *e);
 /* RansEncoder.get_encoded_stream(): flag byte + per-stream sizes + payloads   py_rans.cpp:74-119 */

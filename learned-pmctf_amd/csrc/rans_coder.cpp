@@ -6,15 +6,20 @@
 // folded into the state in reverse at flush so the decoder reads forward.  Out-of-table values use
 // the reference's escape: the row's last symbol as sentinel followed by 4-bit bypass digits.
 //
-// Layout choices (not the reference's): a push is mapped straight to packed 32-bit (start | range)
-// steps in one flat vector (range == 0 marks a 4-bit bypass digit), and flush() walks that vector
-// backwards with two independent passes per word of output, so a full-frame stream (~9 M symbols at
-// 1080p) costs one sequential write and one sequential read of 4 bytes per step.
+// Layout choices (not the reference's): a push only records WHERE its symbols are (the int16 arrays are copied, or
+// borrowed when the caller guarantees their lifetime, pmctf_rans_encoder_set_borrow) — nothing is expanded into
+// per-symbol records.  flush() walks the pushes backwards ONCE, mapping (symbol, CDF row) to its interval on the
+// fly and folding it into the state: a full-frame stream (~9 M symbols at 1080p) costs one sequential read of
+// 4 bytes per symbol.  Division by the interval width is a multiply with a per-interval reciprocal (exact for the
+// states that occur, x < 2^63); the state update is x + q * (2^16 - range) + start, which equals
+// ((x / range) << 16) + x % range + start.  The (CDF row 0, symbol 0) interval — three quarters of a four-step
+// subband stream are such off-mask positions — has its constants in registers.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -27,125 +32,164 @@ constexpr uint32_t kPrecision = 16;
 constexpr uint32_t kBypassPrecision = 4;
 constexpr uint32_t kMaxBypassVal = (1u << kBypassPrecision) - 1;
 constexpr uint64_t kRansL = 1ull << 31;
+// Rans64EncPutBits(.., 4): renormalise when x >= ((L >> 16) << 32) << (16 - 4)
+constexpr uint64_t kBypassXMax = ((kRansL >> 16) << 32) * (uint64_t)(1u << (16 - kBypassPrecision));
 
-// One CDF interval, with the constants that turn x / range into a multiply (Granlund-Montgomery, exact for every
-// 64-bit x): q = (t + ((x - t) >> 1)) >> sh1 with t = mulhi(x, magic); range == 1 and powers of two included.
+// One CDF interval with the constants of its state update.  q = x / range for x < 2^63:
+// q = mulhi(x, magic) >> sh with l = ceil(log2 range), magic = ceil(2^(63+l) / range) (< 2^64), sh = l - 1
+// (error of the product < 2^-l <= 1/range, so the floor is exact); range == 1: q = x.
 struct Entry {
     uint64_t magic;
-    uint32_t start, range;
-    uint32_t sh1;      // l - 1 (l = ceil(log2 range)); unused when range == 1
-    uint32_t pad;
+    uint64_t x_max;    // ((L >> 16) << 32) * range: renormalise first when x >= x_max
+    uint32_t start;
+    uint32_t cmpl;     // 2^16 - range
+    uint32_t sh;
+    uint32_t range;
 };
 
-struct Table {          // a registered (cdfs, sizes) pair; entries[row * cols + value]
-    const int32_t *key_ptr;
+struct Table {          // a registered (cdfs, sizes, offsets) triple; entries[row * cols + value]
     int rows, cols;
     uint64_t checksum;
     uint32_t base;      // first index of this table in the encoder's flat entry array
+    std::vector<int32_t> max_value, offset;     // per row: sizes[row] - 2, offsets[row]
 };
 
-constexpr uint32_t kBypassFlag = 0x80000000u;
+struct Push {           // one encode_with_indexes call
+    const int16_t *sym, *idx;
+    int64_t n;
+    int table;
+    std::unique_ptr<int16_t[]> owned;           // copy of both arrays unless borrowed
+};
 
 struct Part {
-    std::vector<uint32_t> steps;  // entry index, or kBypassFlag | 4-bit digit
     std::vector<uint8_t> stream;
+    std::unique_ptr<uint32_t[]> words;          // scratch of flush(), grown on demand, never initialised
+    size_t cap = 0;
 };
 
 inline Entry make_entry(uint32_t start, uint32_t range) {
     Entry e;
-    e.start = start; e.range = range; e.pad = 0; e.magic = 0; e.sh1 = 0;
+    e.start = start; e.range = range; e.cmpl = (1u << kPrecision) - range; e.magic = 0; e.sh = 0;
+    e.x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)range;
     if (range > 1) {
         uint32_t l = 0;
         while ((1ull << l) < range) ++l;
-        const unsigned __int128 num = ((unsigned __int128)1 << 64) * (((uint64_t)1 << l) - range);
-        e.magic = (uint64_t)(num / range) + 1;
-        e.sh1 = l - 1;
+        const unsigned __int128 num = (unsigned __int128)1 << (63 + l);
+        e.magic = (uint64_t)((num + range - 1) / range);
+        e.sh = l - 1;
     }
     return e;
 }
 
-// row_base: index of this row's first entry in the flat entry array
-inline void push_value(std::vector<uint32_t> &steps, uint32_t row_base, int32_t max_value, int32_t value) {
-    uint32_t raw_val = 0;
-    if (value < 0) {
-        raw_val = (uint32_t)(-2 * value - 1);
-        value = max_value;
-    } else if (value >= max_value) {
-        raw_val = (uint32_t)(2 * (value - max_value));
-        value = max_value;
-    }
-    steps.push_back(row_base + (uint32_t)value);
-    if (value == max_value) {
-        int32_t n_bypass = 0;
-        while ((raw_val >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
-        int32_t val = n_bypass;
-        while (val >= (int32_t)kMaxBypassVal) {
-            steps.push_back(kBypassFlag | kMaxBypassVal);
-            val -= kMaxBypassVal;
-        }
-        steps.push_back(kBypassFlag | (uint32_t)val);
-        for (int32_t j = 0; j < n_bypass; ++j)
-            steps.push_back(kBypassFlag | ((raw_val >> (j * kBypassPrecision)) & kMaxBypassVal));
-    }
+inline uint64_t put(uint64_t x, const Entry &e, uint32_t *&ptr) {
+    if (x >= e.x_max) { *--ptr = (uint32_t)x; x >>= 32; }
+    const uint64_t q = e.range == 1 ? x : (uint64_t)(((unsigned __int128)x * e.magic) >> 64) >> e.sh;
+    return x + q * e.cmpl + e.start;
 }
 
-void flush_part(Part &p, const Entry *entries) {
-    const size_t n = p.steps.size();
-    std::vector<uint32_t> out(n + 2);
-    uint32_t *ptr = out.data() + out.size();
-    uint64_t x = kRansL;
-    const uint32_t *s = p.steps.data();
-    for (size_t i = n; i-- > 0;) {
-        const uint32_t w = s[i];
-        if (!(w & kBypassFlag)) {
-            const Entry &e = entries[w];
-            const uint64_t range = e.range;
-            const uint64_t x_max = ((kRansL >> kPrecision) << 32) * range;
-            if (x >= x_max) { *--ptr = (uint32_t)x; x >>= 32; }
-            uint64_t q;
-            if (range == 1) {
-                q = x;
-            } else {
-                const uint64_t t = (uint64_t)(((unsigned __int128)x * e.magic) >> 64);
-                q = (t + ((x - t) >> 1)) >> e.sh1;
-            }
-            x = (q << kPrecision) + (x - q * range) + e.start;      // ((x / f) << 16) + (x % f) + start
-        } else {
-            const uint32_t val = w & 0xFFFFu;
-            const uint64_t x_max = ((kRansL >> 16) << 32) * (uint64_t)(1u << (16 - kBypassPrecision));
-            if (x >= x_max) { *--ptr = (uint32_t)x; x >>= 32; }
-            x = (x << kBypassPrecision) | val;
-        }
-    }
-    ptr -= 2;
-    ptr[0] = (uint32_t)x;
-    ptr[1] = (uint32_t)(x >> 32);
-    const size_t nbytes = (size_t)((out.data() + out.size()) - ptr) * sizeof(uint32_t);
-    p.stream.resize(nbytes);
-    memcpy(p.stream.data(), ptr, nbytes);
-    p.steps.clear();
+inline uint64_t put_bits(uint64_t x, uint32_t val, uint32_t *&ptr) {
+    if (x >= kBypassXMax) { *--ptr = (uint32_t)x; x >>= 32; }
+    return (x << kBypassPrecision) | val;
+}
+
+// the escape of rans.cpp:100-137 in REVERSE coding order: raw digits high to low, the unary digit count, the sentinel
+inline uint64_t put_escape(uint64_t x, const Entry &sentinel, uint32_t raw_val, uint32_t *&ptr) {
+    int32_t n_bypass = 0;
+    while ((raw_val >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
+    for (int32_t j = n_bypass - 1; j >= 0; --j) x = put_bits(x, (raw_val >> (j * kBypassPrecision)) & kMaxBypassVal, ptr);
+    // forward order: (15)*, then the remainder < 15 -> reversed: remainder first
+    int32_t val = n_bypass;
+    int32_t fifteens = 0;
+    while (val >= (int32_t)kMaxBypassVal) { ++fifteens; val -= kMaxBypassVal; }
+    x = put_bits(x, (uint32_t)val, ptr);
+    for (int32_t j = 0; j < fifteens; ++j) x = put_bits(x, kMaxBypassVal, ptr);
+    return put(x, sentinel, ptr);
 }
 
 }  // namespace
 
 struct pmctf_rans_encoder {
     std::vector<Part> parts;
+    std::vector<Push> pushes;
     std::vector<uint8_t> stream;  // assembled by flush()
     bool multi_thread = false;    // flush() runs in the background (parts in parallel); readers join first
+    bool borrow = false;
     std::thread worker;
     void join() { if (worker.joinable()) worker.join(); }
     ~pmctf_rans_encoder() { join(); }
+
+    std::vector<Entry> entries;   // flat interval table of every registered CDF table
+    std::vector<Table> tables;
+
+    void flush_part(size_t pi) {
+        Part &p = parts[pi];
+        const int64_t nparts = (int64_t)parts.size();
+        // at most 16 bits per symbol plus 6 bypass digits: 40 bits -> 5/4 words
+        size_t total = 0;
+        for (const Push &u : pushes) {
+            const int64_t each = u.n / nparts;
+            total += (size_t)(pi + 1 < (size_t)nparts ? each : u.n - each * (nparts - 1));
+        }
+        const size_t need = total + total / 4 + 16;
+        if (p.cap < need) { p.words.reset(new uint32_t[need]); p.cap = need; }
+        uint32_t *const end = p.words.get() + p.cap;
+        uint32_t *ptr = end;
+        uint64_t x = kRansL;
+        const Entry *const E = entries.data();
+        for (size_t ui = pushes.size(); ui-- > 0;) {
+            const Push &u = pushes[ui];
+            const Table &t = tables[(size_t)u.table];
+            const int64_t each = u.n / nparts;
+            const int64_t b = (int64_t)pi * each;
+            const int64_t cnt = (int64_t)pi + 1 < nparts ? each : u.n - each * (nparts - 1);
+            const int16_t *sym = u.sym + b, *idx = u.idx + b;
+            const int32_t *maxv = t.max_value.data(), *offs = t.offset.data();
+            const Entry *const T = E + t.base;
+            const int cols = t.cols;
+            // (row 0, symbol 0): constants in registers when that value is a regular interval of row 0
+            const int32_t v0 = 0 - offs[0];
+            const bool fast0 = v0 >= 0 && v0 < maxv[0] && T[v0].range > 1;
+            const Entry e0 = fast0 ? T[v0] : Entry{};
+            for (int64_t i = cnt; i-- > 0;) {
+                const int32_t row = idx[i];
+                const int32_t s = sym[i];
+                if (fast0 && (row | s) == 0) {
+                    if (x >= e0.x_max) { *--ptr = (uint32_t)x; x >>= 32; }
+                    const uint64_t q = (uint64_t)(((unsigned __int128)x * e0.magic) >> 64) >> e0.sh;
+                    x = x + q * e0.cmpl + e0.start;
+                    continue;
+                }
+                if (row < 0) continue;
+                const int32_t max_value = maxv[row];
+                const int32_t value = s - offs[row];
+                const Entry *R = T + (size_t)row * cols;
+                if (value >= 0 && value < max_value) {
+                    x = put(x, R[value], ptr);
+                } else {
+                    const uint32_t raw = value < 0 ? (uint32_t)(-2 * value - 1) : (uint32_t)(2 * (value - max_value));
+                    x = put_escape(x, R[max_value], raw, ptr);
+                }
+            }
+        }
+        ptr -= 2;
+        ptr[0] = (uint32_t)x;
+        ptr[1] = (uint32_t)(x >> 32);
+        const size_t nbytes = (size_t)(end - ptr) * sizeof(uint32_t);
+        p.stream.resize(nbytes);
+        memcpy(p.stream.data(), ptr, nbytes);
+    }
 
     void assemble(bool parallel) {
         const size_t np = parts.size();
         if (parallel && np > 1) {
             std::vector<std::thread> th;
-            for (size_t i = 1; i < np; ++i) th.emplace_back([this, i] { flush_part(parts[i], entries.data()); });
-            flush_part(parts[0], entries.data());
+            for (size_t i = 1; i < np; ++i) th.emplace_back([this, i] { flush_part(i); });
+            flush_part(0);
             for (auto &t : th) t.join();
         } else {
-            for (size_t i = 0; i < np; ++i) flush_part(parts[i], entries.data());
+            for (size_t i = 0; i < np; ++i) flush_part(i);
         }
+        pushes.clear();
         size_t total = 0, max_size = 0;
         for (size_t i = 0; i < np; ++i) {
             const size_t sz = parts[i].stream.size();
@@ -168,20 +212,21 @@ struct pmctf_rans_encoder {
         }
     }
 
-    std::vector<Entry> entries;   // flat interval table of every registered CDF table
-    std::vector<Table> tables;
-
-    // find or register (cdfs, sizes); tables are tiny (<= 26 k ints) so the checksum is recomputed per call
-    uint32_t table_base(const int32_t *cdfs, int rows, int cols, const int32_t *sizes) {
+    // find or register (cdfs, sizes, offsets); tables are tiny (<= 26 k ints) so the checksum is recomputed per call
+    int table_index(const int32_t *cdfs, int rows, int cols, const int32_t *sizes, const int32_t *offsets) {
         uint64_t h = 1469598103934665603ull;
         for (long i = 0; i < (long)rows * cols; ++i) h = (h ^ (uint32_t)cdfs[i]) * 1099511628211ull;
         for (int i = 0; i < rows; ++i) h = (h ^ (uint32_t)sizes[i]) * 1099511628211ull;
-        for (const Table &t : tables)
-            if (t.rows == rows && t.cols == cols && t.checksum == h) return t.base;
-        Table t{cdfs, rows, cols, h, (uint32_t)entries.size()};
+        for (int i = 0; i < rows; ++i) h = (h ^ (uint32_t)offsets[i]) * 1099511628211ull;
+        for (size_t k = 0; k < tables.size(); ++k)
+            if (tables[k].rows == rows && tables[k].cols == cols && tables[k].checksum == h) return (int)k;
+        Table t;
+        t.rows = rows; t.cols = cols; t.checksum = h; t.base = (uint32_t)entries.size();
+        t.max_value.resize((size_t)rows); t.offset.assign(offsets, offsets + rows);
         entries.resize(entries.size() + (size_t)rows * cols);
         for (int r = 0; r < rows; ++r) {
             const int n = sizes[r] - 1;          // number of symbols in this row (incl. the escape symbol)
+            t.max_value[(size_t)r] = sizes[r] - 2;
             for (int v = 0; v < cols; ++v) {
                 Entry e = make_entry(0, 1);
                 if (v < n && v + 1 < cols) e = make_entry((uint32_t)cdfs[(size_t)r * cols + v],
@@ -189,8 +234,8 @@ struct pmctf_rans_encoder {
                 entries[t.base + (size_t)r * cols + v] = e;
             }
         }
-        tables.push_back(t);
-        return t.base;
+        tables.push_back(std::move(t));
+        return (int)tables.size() - 1;
     }
 };
 
@@ -216,7 +261,13 @@ void pmctf_rans_encoder_destroy(pmctf_rans_encoder *e) { delete e; }
 int pmctf_rans_encoder_reset(pmctf_rans_encoder *e) {
     if (!e) return PMCTF_RANS_EINVAL;
     e->join();
-    for (auto &p : e->parts) p.steps.clear();
+    e->pushes.clear();
+    return PMCTF_RANS_OK;
+}
+
+int pmctf_rans_encoder_set_borrow(pmctf_rans_encoder *e, int borrow) {
+    if (!e) return PMCTF_RANS_EINVAL;
+    e->borrow = borrow != 0;
     return PMCTF_RANS_OK;
 }
 
@@ -227,24 +278,22 @@ int pmctf_rans_encoder_encode_with_indexes(pmctf_rans_encoder *e, const int16_t 
         return PMCTF_RANS_EINVAL;
     for (int r = 0; r < cdf_rows; ++r)
         if (cdf_sizes[r] < 2 || cdf_sizes[r] > cdf_cols) return PMCTF_RANS_EINVAL;
+    int32_t hi = -1;
+    for (int64_t i = 0; i < n; ++i) hi = indexes[i] > hi ? indexes[i] : hi;      // rows are checked now, coded at flush
+    if (hi >= cdf_rows) return PMCTF_RANS_EINVAL;
     e->join();
-    const uint32_t base = e->table_base(cdfs, cdf_rows, cdf_cols, cdf_sizes);
-    if ((uint64_t)e->entries.size() >= kBypassFlag) return PMCTF_RANS_EINVAL;
-    const int64_t nparts = (int64_t)e->parts.size();
-    const int64_t each = n / nparts;
-    for (int64_t pi = 0; pi < nparts; ++pi) {
-        const int64_t b = pi * each;
-        const int64_t cnt = pi < nparts - 1 ? each : n - each * (nparts - 1);
-        auto &steps = e->parts[(size_t)pi].steps;
-        steps.reserve(steps.size() + (size_t)cnt + (size_t)cnt / 8 + 16);
-        for (int64_t i = b; i < b + cnt; ++i) {
-            const int32_t row = indexes[i];
-            if (row < 0) continue;
-            if (row >= cdf_rows) return PMCTF_RANS_EINVAL;
-            push_value(steps, base + (uint32_t)row * (uint32_t)cdf_cols, cdf_sizes[row] - 2,
-                       (int32_t)symbols[i] - offsets[row]);
-        }
+    Push u;
+    u.table = e->table_index(cdfs, cdf_rows, cdf_cols, cdf_sizes, offsets);
+    u.n = n;
+    if (e->borrow) {
+        u.sym = symbols; u.idx = indexes;
+    } else {
+        u.owned.reset(new int16_t[2 * (size_t)n + 2]);
+        memcpy(u.owned.get(), symbols, (size_t)n * sizeof(int16_t));
+        memcpy(u.owned.get() + n, indexes, (size_t)n * sizeof(int16_t));
+        u.sym = u.owned.get(); u.idx = u.owned.get() + n;
     }
+    e->pushes.push_back(std::move(u));
     return PMCTF_RANS_OK;
 }
 

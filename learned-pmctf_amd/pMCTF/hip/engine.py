@@ -102,6 +102,7 @@ class RangeCoderPool:
             e = _lib.rans().pmctf_rans_encoder_create(0, 1)
             if not e:
                 raise RuntimeError("pmctf_rans_encoder_create failed")
+            _lib.rans().pmctf_rans_encoder_set_borrow(e, 1)     # the pinned symbol buffers live as long as the job
             self.local.enc = e
         return e
 

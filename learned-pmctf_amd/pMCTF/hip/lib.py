@@ -73,6 +73,7 @@ _RANS_SIGS = {
     "pmctf_rans_encoder_destroy": (None, [vp]),
     "pmctf_rans_encoder_reset": (ci, [vp]),
     "pmctf_rans_encoder_encode_with_indexes": (ci, [vp, vp, vp, i64, vp, ci, ci, vp, vp]),
+    "pmctf_rans_encoder_set_borrow": (ci, [vp, ci]),
     "pmctf_rans_encoder_flush": (ci, [vp]),
     "pmctf_rans_encoder_stream_size": (i64, [vp]),
     "pmctf_rans_encoder_get_encoded_stream": (ci, [vp, vp, i64]),

@@ -153,6 +153,23 @@ def test_host_range_coder_matches_oracle_and_round_trips(parts, n):
         size = lib.rans().pmctf_rans_encoder_write_file(ec.encoder, hdr, len(hdr), path.encode())
         assert size == len(hdr) + len(s) == os.path.getsize(path)
         assert open(path, "rb").read() == hdr + s
+        # borrow mode (the product's writer threads): the caller's arrays are read at flush(), same bytes
+        R = lib.rans()
+        eb = R.pmctf_rans_encoder_create(0, parts)
+        assert R.pmctf_rans_encoder_set_borrow(eb, 1) == 0
+        cdf_n, ln_n, off_n = (np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in (cdf, ln, off))
+        for a, b in ((0, n // 3), (n // 3, n)):
+            assert R.pmctf_rans_encoder_encode_with_indexes(eb, sym[a:].ctypes.data, idx[a:].ctypes.data, b - a,
+                                                            cdf_n.ctypes.data, cdf_n.shape[0], cdf_n.shape[1],
+                                                            ln_n.ctypes.data, off_n.ctypes.data) == 0
+        assert R.pmctf_rans_encoder_flush(eb) == 0
+        buf = np.empty(R.pmctf_rans_encoder_stream_size(eb), np.uint8)
+        assert R.pmctf_rans_encoder_get_encoded_stream(eb, buf.ctypes.data, buf.size) == 0 and buf.tobytes() == s
+        bad = np.full(4, cdf_n.shape[0], np.int16)            # a CDF row out of range is refused at the push
+        assert R.pmctf_rans_encoder_encode_with_indexes(eb, sym.ctypes.data, bad.ctypes.data, 4, cdf_n.ctypes.data,
+                                                        cdf_n.shape[0], cdf_n.shape[1], ln_n.ctypes.data,
+                                                        off_n.ctypes.data) == -1
+        R.pmctf_rans_encoder_destroy(eb)
 
 
 def test_stream_framing_and_helpers():
