@@ -70,14 +70,19 @@ class SymbolStream:
 
     def to_host(self):
         """Asynchronous D2H into pinned memory; returns (sym, idx, event)."""
-        assert self.off == self.total, (self.off, self.total)
         hs = torch.empty(self.total, dtype=torch.int16, pin_memory=True)
         hi = torch.empty(self.total, dtype=torch.int16, pin_memory=True)
-        hs.copy_(self.sym, non_blocking=True)
-        hi.copy_(self.idx, non_blocking=True)
+        self.copy_to(hs, hi)
         ev = torch.cuda.Event()
         ev.record()
         return hs, hi, ev
+
+    def copy_to(self, hs, hi):
+        """the two asynchronous D2H copies alone, into the caller's pinned buffers (a captured launch plan records
+        them as copy nodes and marks completion with an event behind the whole segment)"""
+        assert self.off == self.total == hs.numel() == hi.numel(), (self.off, self.total, hs.numel())
+        hs.copy_(self.sym, non_blocking=True)
+        hi.copy_(self.idx, non_blocking=True)
 
 
 class BitSink:
@@ -140,6 +145,10 @@ class RangeCoderPool:
     def submit(self, stream, tables, header, path, keep=False):
         hs, hi, ev = stream.to_host()
         return self.pool.submit(self._run, hs, hi, ev, list(stream.segments), tables, header, path, keep)
+
+    def submit_host(self, hs, hi, ev, segments, tables, header, path, keep=False):
+        """the symbols are (being) copied into the pinned buffers hs / hi; `ev` marks the end of those copies"""
+        return self.pool.submit(self._run, hs, hi, ev, segments, tables, header, path, keep)
 
     def submit_planes(self, stream, nplanes, groups, tables, keep=False):
         """One device stream holds the symbols of `nplanes` independently coded planes (every push is plane-major, as
@@ -209,6 +218,16 @@ class HipEngine:
         self.pu_fused = os.environ.get("PMCTF_PU_FUSED", "1") != "0"     # one launch per PredictUpdate + lifting step
         self.pu_fused_max_px = int(os.environ.get("PMCTF_PU_FUSED_MAX_PX", "400000"))
         self.post_process_max_px = 8 * 1152 * 1920      # pixels per post-processing launch group (4.5 GB per 64-ch map)
+        # encode_one_stage replays captured launch plans (HIP graphs, pMCTF.hip.pair_plan) from the second pair of a
+        # configuration on: luma and chroma coders on two streams, no per-launch host work
+        self.use_graphs = os.environ.get("PMCTF_GRAPHS", "1") != "0"
+        self.pair_plans = {}
+        self.capture_stream = torch.cuda.Stream(device=self.dev)
+        # luma carries the longest symbol stream: its coder gets the high-priority queue so that the stream reaches the
+        # host range coder early (measured: 5.41 vs 5.38 frames/s on the 1080p GOP-16 encode)
+        prio = int(os.environ.get("PMCTF_LUMA_PRIORITY", "-1"))
+        self.pair_streams = (torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Stream(device=self.dev))
+        self.syn_after_analysis = os.environ.get("PMCTF_SYN_AFTER_ANALYSIS", "1") != "0"
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
 
@@ -453,11 +472,24 @@ class HipEngine:
         bit estimates (two device float64: y, z) instead of a symbol stream.
         dpb may be a zero-argument callable: it is evaluated after the motion ESTIMATION (which needs no context), so
         a caller that receives the context from another GPU overlaps the wait with SpyNet (pmctf_dist relay)."""
-        s = min(self.num_me_stages - 1, stage_idx)
-        q_enc, q_dec = self.get_mv_y_q(q_index, s, inference=not estimate)
         est_mv = self.spynet(cur_y, ref_y, me_downsample=me_downsample)
         if callable(dpb):
             dpb = dpb()
+        return self.motion_code(est_mv, dpb, stage_idx, q_index, estimate, me_downsample)
+
+    def motion_estimate(self, ref_y, cur_y, me_downsample=1):
+        """the motion ESTIMATION of compress_mv (pMCTF_L.py:452-460): optic_flow(cur, ref)"""
+        return self.spynet(cur_y, ref_y, me_downsample=me_downsample)
+
+    def mv_symbol_count(self, height, width, me_downsample=1):
+        """symbols of one motion stream (z + four y parts) for a luma plane of height x width"""
+        h, w = height // me_downsample, width // me_downsample
+        return (h // 64) * (w // 64) * 64 + 4 * 16 * (h // 16) * (w // 16)
+
+    def motion_code(self, est_mv, dpb, stage_idx=0, q_index=0, estimate=False, me_downsample=1):
+        """the motion CODEC of compress_mv (pMCTF_L.py:462-495): everything after the motion estimation"""
+        s = min(self.num_me_stages - 1, stage_idx)
+        q_enc, q_dec = self.get_mv_y_q(q_index, s, inference=not estimate)
         mv_y = self.mv_enc(s, est_mv, self.to_nhwc_input(dpb["mv_feature"]), q_enc)
         mv_z = self.mv_hyper_enc(s, mv_y)
         _, hy, wy, _ = mv_y.shape

@@ -1,0 +1,183 @@
+"""Captured launch plans for `encode_one_stage` (write-stream branch, pMCTF_L.py:553-637).
+
+A harness calls `encode_one_stage` once per frame pair and looks at the bit counts before the next call
+(test_pMCTF_flex.py:236-249), so every pair is a batch of its own: ~3 000 launches, a third of them on the small
+planes of the wavelet pyramid, where the host cannot enqueue as fast as the GPU executes and where a lone coder
+leaves most of the 256 CUs idle.  A `PairPlan` records the launches of one configuration (plane shapes, temporal
+stage, rate point, with/without L, first/later pair of the motion-context chain) ONCE as HIP graphs — the same
+engine code runs under stream capture — and replays them for every later pair of that configuration:
+
+    main stream   inputs -> [motion estimation] -> [motion codec + D2H of its symbols]
+    luma stream       [lifting + H analysis + D2H] (-> [L analysis + D2H])      .. -> [synthesis] -> results
+    chroma stream     [lifting + H analysis + D2H] (-> [L analysis + D2H])      .. -> [synthesis] -> results
+
+Luma and chroma are independent once the motion field exists, so their graphs run concurrently: the small-plane
+launches of one fill the CUs the other leaves idle, and replay costs the host microseconds, not milliseconds.
+The synthesis transforms (needed for the returned reconstructions only) start when both analyses are done, so
+that every symbol stream reaches the host range coder as early as possible and the coder's tail hides under GPU
+work.  A graph replays the very kernels the stream path launches, in the same order with the same arguments:
+results are bit-identical (tests/test_gpu_engine.py::test_pair_plan_equals_stream_launches).
+
+Static storage: a plan owns its input planes, the pinned host buffers of its symbol streams and (inside the
+graphs' private pools) every intermediate; results are copied out into fresh tensors per call, because the
+caller keeps them across the GOP (test_pMCTF_flex.py:225-226).
+"""
+import torch
+
+
+class _Capture:
+    """Cuts the launches issued by ordinary Python code into a sequence of HIP graphs."""
+
+    def __init__(self):
+        self.graphs = []
+        self.g = None
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        self.g.capture_begin(capture_error_mode="thread_local")
+
+    def cut(self):
+        self.end()
+        self.begin()
+
+    def end(self):
+        self.g.capture_end()
+        self.graphs.append(self.g)
+        self.g = None
+
+    def abort(self):
+        if self.g is not None:
+            try:
+                self.g.capture_end()
+            except Exception:  # noqa: BLE001 - the original error is the one to report
+                pass
+            self.g = None
+
+
+class PairPlan:
+    def __init__(self, eng, ry, rc, chained, code_lt, stage_idx, q_index, me_downsample=1):
+        """ry / rc: a luma (1,1,H,W) and a chroma (2,1,H/2,W/2) plane of the size to plan for (shapes only).
+        Must be called when every layer this configuration uses has been packed already (i.e. after one pair of the
+        configuration went through the stream path) — packing synchronises, which a capture cannot."""
+        self.eng = eng
+        dev = eng.dev
+        self.chained, self.code_lt = chained, code_lt
+        _, _, H, W = ry.shape
+        new = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=dev)
+        self.in_ry, self.in_cy, self.in_rc, self.in_cc = new(ry), new(ry), new(rc), new(rc)
+        self.in_dpb = {"mv_feature": None, "ref_mv_y": None}
+        if chained:
+            h, w = H // me_downsample, W // me_downsample
+            self.in_dpb = {"mv_feature": torch.empty((1, h // 4, w // 4, 64), dtype=torch.float32, device=dev).permute(0, 3, 1, 2),
+                           "ref_mv_y": torch.empty((1, h // 16, w // 16, 64), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)}
+        pin = lambda n: (torch.empty(n, dtype=torch.int16, pin_memory=True), torch.empty(n, dtype=torch.int16, pin_memory=True))
+        n_mv = eng.mv_symbol_count(H, W, me_downsample)
+        n_y, n_c = eng.pwave_symbol_count(1, H, W), eng.pwave_symbol_count(2, H // 2, W // 2)
+        kinds = ("H", "L") if code_lt else ("H",)
+        self.host = {"mv": pin(n_mv)}
+        for k in kinds:
+            self.host[k] = pin(n_y)
+            self.host[k + "c"] = pin(n_c)
+        self.segments = {}          # job name -> SymbolStream.segments of that bitstream
+        cap = _Capture()
+        cur = torch.cuda.current_stream(dev)
+        side = eng.capture_stream
+        side.wait_stream(cur)
+        try:
+            with torch.cuda.stream(side):
+                cap.begin()
+                est = eng.motion_estimate(self.in_ry, self.in_cy, me_downsample)
+                cap.cut()
+                mv = eng.motion_code(est, self.in_dpb, stage_idx, q_index, False, me_downsample)
+                mv["stream"].copy_to(*self.host["mv"])
+                self.segments["mv"] = list(mv["stream"].segments)
+                cap.end()
+                self.g_me, self.g_mv = cap.graphs
+                self.mv = mv
+
+                def analysis(ref, cur_, chroma):
+                    c = _Capture()
+                    suffix = "c" if chroma else ""
+
+                    def on_stream(kind, stream):
+                        stream.copy_to(*self.host[kind + suffix])
+                        self.segments[kind + suffix] = list(stream.segments)
+                        if kind == "H" and code_lt:
+                            c.cut()
+                    c.begin()
+                    try:
+                        out = eng.compress_one_stage(ref, cur_, code_lt, mv["mv_hat"], chroma, stage_idx, q_index, False,
+                                                     on_stream=on_stream, defer=True)
+                        c.end()
+                    except BaseException:
+                        c.abort()
+                        raise
+                    s = _Capture()
+                    s.begin()
+                    try:
+                        out["finish"]()
+                        s.end()
+                    except BaseException:
+                        s.abort()
+                        raise
+                    return out, c.graphs, s.graphs[0]
+                self.luma, self.g_luma, self.g_luma_syn = analysis(self.in_ry, self.in_cy, False)
+                self.chroma, self.g_chroma, self.g_chroma_syn = analysis(self.in_rc, self.in_cc, True)
+        except BaseException:
+            cap.abort()
+            raise
+        cur.wait_stream(side)
+
+    def run(self, ry, cy, rc, cc, dpb, submit, on_dpb=None):
+        """Replays the plan on the caller's frames.  dpb: the motion context (dict of logical-NCHW tensors, or a
+        zero-argument callable delivering it after the motion estimation).  submit(job, hs, hi, event, segments) hands one
+        bitstream's pinned symbol buffers to the range coder.  Returns the tensors of encode_one_stage's result."""
+        eng = self.eng
+        A, B = eng.pair_streams
+        main = torch.cuda.current_stream(eng.dev)
+        for dst, src in ((self.in_ry, ry), (self.in_cy, cy), (self.in_rc, rc), (self.in_cc, cc)):
+            dst.copy_(src)
+        self.g_me.replay()
+        if callable(dpb):
+            dpb = dpb()
+        if self.chained:
+            for k in ("mv_feature", "ref_mv_y"):
+                self.in_dpb[k].copy_(dpb[k])
+        self.g_mv.replay()
+        mark = lambda: torch.cuda.Event()
+        e_mv = mark()
+        e_mv.record(main)
+        fresh = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=eng.dev)
+        mv = self.mv
+        res = {"mv_hat": fresh(mv["mv_hat"]), "mv_feature": fresh(mv["mv_feature"]), "mv_y_hat": fresh(mv["mv_y_hat"])}
+        for k in ("mv_hat", "mv_feature", "mv_y_hat"):
+            res[k].copy_(mv[k])
+        if on_dpb is not None:
+            on_dpb({"mv_feature": res["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": res["mv_y_hat"].permute(0, 3, 1, 2)})
+        submit("mv", *self.host["mv"], e_mv, self.segments["mv"])
+        kinds = ("H", "L") if self.code_lt else ("H",)
+        done = []
+        for st, graphs, suffix in ((A, self.g_luma, ""), (B, self.g_chroma, "c")):
+            st.wait_event(e_mv)
+            with torch.cuda.stream(st):
+                for g, kind in zip(graphs, kinds):
+                    g.replay()
+                    ev = mark()
+                    ev.record(st)
+                    submit(kind + suffix, *self.host[kind + suffix], ev, self.segments[kind + suffix])
+                done.append(ev)
+        if eng.syn_after_analysis:      # every symbol stream is on its way before any synthesis transform starts
+            A.wait_event(done[1])
+            B.wait_event(done[0])
+        for st, g, out, suffix in ((A, self.g_luma_syn, self.luma, ""), (B, self.g_chroma_syn, self.chroma, "c")):
+            # the result tensors belong to the caller's stream (allocated there); only the copies run on the side stream
+            names = ("L_t_hat" if self.code_lt else "L_t", "H_t_hat")
+            outs = [fresh(out[n]) for n in names]
+            with torch.cuda.stream(st):
+                g.replay()
+                for o, n in zip(outs, names):
+                    o.copy_(out[n])
+            res["L_t" + suffix], res["H_t" + suffix] = outs
+        main.wait_stream(A)
+        main.wait_stream(B)
+        return res

@@ -104,11 +104,14 @@ def encode_gops_batched(codec, gops, pic_height, pic_width, q_index, bin_folders
 
 
 def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_decoding=True, psize=128,
-               on_pair=None, me_downsample=1):
+               on_pair=None, me_downsample=1, store_only=False):
     """frames: list (len = GOP size, power of two) of [Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] padded tensors.
     Returns dict(bits[], frames_coded (after forward), results[] per pair in coding order).
     me_downsample > 1: the schedule of test_pMCTF_CA.py:code_one_gop (motion at reduced resolution; pad the frames to
-    ca_psize(me_downsample) and pass that as psize)."""
+    ca_psize(me_downsample) and pass that as psize).
+    store_only=True: a caller that keeps the results of every pair WITHOUT the harness's two prints (not what
+    test_pMCTF_flex.py does): with the codec's opt-in deferral (lazy_stages) the pairs of a stage are then coded as one
+    batch."""
     gop = len(frames)
     stages = int(round(math.log2(gop)))
     assert 2 ** stages == gop and gop >= 2
@@ -116,6 +119,7 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
     bits = [None] * gop
     bits_mv = [None] * gop
     results = []
+    log = []
     num_frames = gop
     for stage_idx in range(stages):
         num_frames //= 2
@@ -142,20 +146,33 @@ def encode_gop(codec, frames, pic_height, pic_width, q_index, bin_folder, skip_d
             frames_coded[i_ref] = [r["L_t"], r["L_tc"], None]
             frames_coded[i_cur] = [r["H_t"], r["H_tc"], r["mv_hat"]]
             dpb = r["dpb"]
-            # as the harness does (test_pMCTF_flex.py:236-258): the numbers are only stored here, not looked at — a codec
-            # that defers its results (the MI355X build batches the pairs of a stage) keeps deferring
-            bits[i_cur] = r["bit_H"] + r["bit_ME"]
-            bits_mv[i_cur] = r["bit_ME"]
+            # what the harness does with the numbers of every pair, statement for statement (test_pMCTF_flex.py:236-258):
+            # the two f-strings it prints LOOK at the bit counts right here, before the next call
+            curr_bits = r["bit_H"] + r["bit_ME"]
+            if isinstance(curr_bits, torch.Tensor):
+                curr_bits = curr_bits.item()
+            tmp = r["bit_ME"] / curr_bits
+            if not store_only:
+                log.append(f"percentage MV: {tmp*100} %")
+            bits[i_cur] = curr_bits
+            bit_me = r["bit_ME"].item() if isinstance(r["bit_ME"], torch.Tensor) else r["bit_ME"]
+            bits_mv[i_cur] = bit_me
+            if not store_only:
+                log.append(f"Frame {i_cur}: {curr_bits / (pic_height * pic_width)} bpp")
             if code_lt:
-                bits[i_ref] = r["bit_L"]
+                curr_bits = r["bit_L"]
+                if isinstance(curr_bits, torch.Tensor):
+                    curr_bits = curr_bits.item()
+                bits[i_ref] = curr_bits
                 bits_mv[i_ref] = 0.0
             results.append(r)
             if on_pair is not None:
                 on_pair(stage_idx, i_ref, i_cur, r)
-    bits = [None if b is None else float(b) for b in bits]             # the harness's log step (generate_log_json)
+    bits = [None if b is None else float(b) for b in bits]
     bits_mv = [None if b is None else float(b) for b in bits_mv]
     frames_coded = [[t if t is None or isinstance(t, torch.Tensor) else t.force() for t in fc] for fc in frames_coded]
-    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
+    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages,
+            "log": log}
 
 
 def decode_gop(codec, frames_coded, luma_stage0=False):

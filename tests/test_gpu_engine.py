@@ -627,6 +627,58 @@ def test_batched_stage_equals_pair_by_pair(cuda):
                 np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
 
 
+def test_pair_plan_equals_stream_launches(cuda):
+    """encode_one_stage replays captured launch plans (HIP graphs, luma / chroma coders on two streams) from the second
+    pair of a configuration on (pMCTF.hip.pair_plan).  GOP 8 with four ME stages at 128x128, coded three times: stream
+    launches only (plans off), the GOP that records the plans, and a GOP that only replays — every file, bit count,
+    symbol trace and tensor identical, and the replayed GOP really went through the plans."""
+    import pmctf_gop
+    from pMCTF.hip import pair_plan
+    net, _ = product_model(4)
+    eng = net.engine()
+    eng.keep_streams = True
+    fr = frames(W, H, 8, device="cuda", seed=29)
+    fr2 = frames(W, H, 8, device="cuda", seed=31)
+
+    def gop(frames_):
+        with tempfile.TemporaryDirectory() as td:
+            enc = pmctf_gop.encode_gop(net, frames_, H, W, 3, td)
+            return enc, {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+    eng.use_graphs = False
+    ref, ref_files = gop(fr)
+    ref2, ref2_files = gop(fr2)
+    eng.use_graphs = True
+    eng.pair_plans.clear()
+    runs = []
+    orig = pair_plan.PairPlan.run
+    pair_plan.PairPlan.run = lambda self, *a, **k: (runs.append(self), orig(self, *a, **k))[1]
+    try:
+        first, first_files = gop(fr)          # stage 0: pair 0 and pair 1 record (unchained / chained), pairs 2, 3 replay
+        assert len(runs) == 2 + 0 + 0 and len(eng.pair_plans) == 2 + 2 + 1
+        del runs[:]
+        second, second_files = gop(fr2)       # other frames: every pair replays a plan recorded on the first GOP
+        assert len(runs) == 7
+    finally:
+        pair_plan.PairPlan.run = orig
+    for enc, files, r, rf in ((first, first_files, ref, ref_files), (second, second_files, ref2, ref2_files)):
+        assert files == rf and len(files) == 3 * 7 + 2
+        assert enc["bits"] == r["bits"] and enc["bits_mv"] == r["bits_mv"]
+        for a, b in zip(enc["frames_coded"], r["frames_coded"]):
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or torch.equal(x, y)
+        for ra, rb in zip(enc["results"], r["results"]):
+            assert torch.equal(ra["dpb"]["mv_feature"], rb["dpb"]["mv_feature"])
+            assert torch.equal(ra["dpb"]["ref_mv_y"], rb["dpb"]["ref_mv_y"])
+            for k in rb["files"]:
+                assert ra["files"][k] == rb["files"][k], k
+                assert np.array_equal(ra["traces"][k][0], rb["traces"][k][0]) and \
+                    np.array_equal(ra["traces"][k][1], rb["traces"][k][1]), k
+    rec = pmctf_gop.decode_gop(net, [list(f) for f in second["frames_coded"]])
+    rec_ref = pmctf_gop.decode_gop(net, [list(f) for f in ref2["frames_coded"]])
+    for a, b in zip(rec, rec_ref):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("gop", [16, 8])
 def test_headline_config_stage_batched_vs_reference(cuda, gop):
     """The stage-batched schedule (pairs of a temporal stage as one batch; bench.py's auxiliary figure) on the headline
@@ -953,11 +1005,12 @@ def test_estimate_only_branch_of_encode_one_stage(setup):
 
 
 def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
-    """The product's default mode: encode_one_stage hands back deferred results, the pairs a harness passes one by one
-    are collected per temporal stage and coded as ONE batch when a value is first needed (pMCTF.hip.deferred).  The
-    harness loop of test_pMCTF_flex.py (pmctf_gop.encode_gop) must give exactly the eager results — files, bit counts,
-    subband tree, reconstruction — with one encode_stage_pairs call per stage; and looking at a result early simply
-    codes what has been collected so far."""
+    """The product's OPT-IN mode (lazy_stages / PMCTF_LAZY=1): encode_one_stage hands back deferred results, the pairs a
+    caller passes one by one are collected per temporal stage and coded as ONE batch when a value is first needed
+    (pMCTF.hip.deferred).  A loop that only STORES the results (pmctf_gop.encode_gop(store_only=True) — the harness loop
+    without its two prints) must give exactly the eager results — files, bit counts, subband tree, reconstruction —
+    with one encode_stage_pairs call per stage; the harness's own loop, whose prints look at every pair's bit count
+    (test_pMCTF_flex.py:240,248), codes pair by pair; and looking at a result early codes what has been collected."""
     import pmctf_gop
     net, _ = product_model(4, lazy=False)
     fr = frames(W, H, 8, device="cuda", seed=41)
@@ -970,7 +1023,11 @@ def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
     orig = net.encode_stage_pairs
     net.encode_stage_pairs = lambda pairs, *a, **k: (calls.append(len(pairs)), orig(pairs, *a, **k))[1]
     with tempfile.TemporaryDirectory() as td:
-        lazy = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+        loud = pmctf_gop.encode_gop(net, fr, H, W, 3, td)     # the harness's loop with its prints: every pair on its own
+        assert calls == [1] * 7 and loud["bits"] == ref["bits"], calls
+        del calls[:]
+    with tempfile.TemporaryDirectory() as td:
+        lazy = pmctf_gop.encode_gop(net, fr, H, W, 3, td, store_only=True)
         assert calls == [4, 2, 1], calls                     # one batch per temporal stage
         files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
         rec = pmctf_gop.decode_gop(net, [list(f) for f in lazy["frames_coded"]])
@@ -1003,7 +1060,7 @@ def test_deferred_stage_batching_behind_the_drop_in_api(cuda):
     net.lazy_stages = True
     del calls[:]
     with tempfile.TemporaryDirectory() as td:
-        lazy2 = pmctf_gop.encode_gop(net, fr[:4], H, W, 3, td, me_downsample=2)
+        lazy2 = pmctf_gop.encode_gop(net, fr[:4], H, W, 3, td, me_downsample=2, store_only=True)
         assert calls == [2, 1]
         assert {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))} == ref2_files
     assert lazy2["bits"] == ref2["bits"]
