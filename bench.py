@@ -4,17 +4,28 @@
 One "step" = one full GOP-16 encode of 1920x1080 4:2:0 frames at q_index=3, inputs already resident in HBM,
 bitstreams written by the host range coder.
 
-`value` is measured through the DROP-IN path: pMCTF.encode_one_stage called pair by pair, exactly the loop of the
-reference's harness (test_pMCTF_flex.py:214-223) — 15 pairs + the final L frame per GOP.  (Inside the model the calls
-are deferred and the pairs of a temporal stage coded as one batch, pMCTF.hip.deferred; the harness cannot tell.)  In the
-same run, after the timed region, rank 0 also measures (auxiliary figures, never `value`):
-  * `eager_pair_by_pair` — the same loop with deferral off (every call finished before it returns);
-  * `luma_chroma_two_streams` — the default loop with the luma and chroma coders on two HIP streams;
-  * `stage_batched`     — all pairs of a temporal stage in one call (pMCTF.encode_stage_pairs): same files and bits,
-                          larger launches;
+`value` times what the UNMODIFIED reference harness gets: pmctf_gop.encode_gop restates its loop statement for
+statement (test_pMCTF_flex.py:196-258) — pMCTF.encode_one_stage once per frame pair, 15 pairs + the final L frame per
+GOP, and after EVERY call the two f-strings the script prints, which look at that pair's bit counts (:240, :248).
+Every pair is therefore finished (files written, sizes known) before the next call starts.  The model is in its default
+mode: finished tensors and Python floats per call; from the second pair of a configuration on it replays captured
+launch plans (HIP graphs, luma / chroma coders of the pair on two streams, pMCTF.hip.pair_plan).
+In the same run, after the timed region, rank 0 also measures (auxiliary figures, never `value`):
+  * `roofline` / `stream_launches_single_stream` — the same loop with the plans off: plain stream launches on ONE
+                          stream, the dominant convolution bracketed by HIP events on that stream (with the plans on,
+                          luma and chroma kernels share the GPU, which per-kernel events cannot separate);
+  * `cpu_baseline`      — the oracle's ATen-CPU restatement timed on one full-size 1080p pair on the host cores;
+and, while the wall-clock budget for auxiliary legs (--aux_budget_s) lasts:
+  * `deferred_store_only` — a caller that only STORES the results (the harness loop WITHOUT its two prints) with the
+                          model's opt-in deferral: the pairs of a temporal stage coded as one batch;
+  * `stage_batched`     — all pairs of a temporal stage in one call (pMCTF.encode_stage_pairs);
   * `cross_gop_batched` — the same with stage s of K closed GOPs in one call (pmctf_gop.encode_gops_batched);
-  * `cpu_baseline`      — the oracle's ATen-CPU restatement timed on one full-size 1080p pair on the host cores.
-N GPUs encode N independent GOPs (closed GOPs are independent units: no data-path collective; weak scaling).
+  * `decode_pair`       — one 1080p pair with skip_decoding=False: the real decoder's time;
+  * `aux_profiles`      — the reduced-precision arithmetic profiles (no parity claim).
+N GPUs encode N independent GOPs (closed GOPs are independent units: no data-path collective; weak scaling) — that is
+`value`; with N > 1 the same ranks then time the north-star layout as `pair_sharded`: ONE GOP, the pairs of each
+temporal stage spread over the ranks, motion context relayed rank to rank, one all-gather of the subband tree per
+stage over RCCL (strong scaling).
 Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -40,8 +51,7 @@ def cpu_baseline(width, height, gop, q_index):
     """The oracle's restatement with the ATen CPU ops the reference itself calls (kind "port"), timed on the host cores
     on a bounded sample of the SAME workload: one full-size H pair of the 1080p sequence (stage 0, no L).  The pair that
     also codes L does one more coded frame: t_HL = t_H * (2*10186 + 902.5) / (10186 + 902.5) by the conv work of
-    BASELINE.md §3; GOP time = (gop-2)*t_H + t_HL.  The former 448x256 sample (cache-resident, optimistic) is timed as
-    well and reported beside it."""
+    BASELINE.md §3; GOP time = (gop-2)*t_H + t_HL."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import pmctf_synth
@@ -56,29 +66,17 @@ def cpu_baseline(width, height, gop, q_index):
     sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
     orc = Oracle(sd, 1, "torch")
     dpb = {"mv_feature": None, "ref_mv_y": None}
-
-    def time_pair(w, h, code_lt):
-        fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(w, h, 2)]
-        with torch.no_grad():
-            t0 = time.time()
-            orc.encode_one_stage(fr[0], fr[1], code_lt, dpb, pic_width=w, pic_height=h, q_index=q_index)
-            return time.time() - t0
-
+    fr = [list(pmctf_synth.frames_to_tensors(f)) for f in pmctf_synth.synth_yuv420(width, height, 2)]
+    with torch.no_grad():
+        t0 = time.time()
+        orc.encode_one_stage(fr[0], fr[1], False, dpb, pic_width=width, pic_height=height, q_index=q_index)
+        t_h = time.time() - t0
     ratio = (2 * _W_FRAME + _W_MOTION) / (_W_FRAME + _W_MOTION)
-    t_small = time_pair(448, 256, False)
-    t_small_hl = time_pair(448, 256, True)
-    t_h = time_pair(width, height, False)
     t_gop = (gop - 2) * t_h + ratio * t_h
-    ph, pw = 256, 512
-    PH, PW = -(-height // 128) * 128, -(-width // 128) * 128
-    scale = (PH * PW) / (ph * pw)
     return {"value": gop / t_gop, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle (ATen CPU ops, as the reference's CPU path) on ONE full-size {width}x{height} H pair: "
                       f"t_H = {t_h:.1f} s; GOP = {gop - 2}*t_H + t_HL with t_HL = {ratio:.3f}*t_H (conv work ratio)",
-            "t_h_pair_s": t_h,
-            "small_sample_value": gop / (((gop - 2) * t_small + t_small_hl) * scale),
-            "small_sample": f"one H pair ({t_small:.1f} s) and one H+L pair ({t_small_hl:.1f} s) at 448x256 scaled "
-                            f"x{scale:.1f} by padded pixels (cache-resident: optimistic)"}
+            "t_h_pair_s": t_h}
 
 
 def spawn_ranks(args):
@@ -93,22 +91,43 @@ def spawn_ranks(args):
     return subprocess.call(cmd)
 
 
-def roofline_of(events, kernel, traffic):
-    """dominant-kernel roofline from HIP events recorded on the launch stream inside the timed region"""
+def roofline_of(events, kernels, traffic, probe_pass):
+    """dominant-kernel roofline from HIP events recorded on the launch stream; `kernels`: what the C side launched for
+    those convolutions (pmctf_conv2d_last_launch), with counts"""
     durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in events]
     flops_all = [f for _, _, f in events]
     # launches of this convolution can differ in batch size: rate = total FLOP / total time
     achieved = sum(flops_all) / sum(durs) / 1e12 if durs else None     # None: no launch of that shape (small frames)
-    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": "3x3 112->112 convolution on 576x960 luma subband planes, f32 MFMA 16x16x4; launched as: "
+                                       + "; ".join(f"{n}x {k}" for k, n in sorted(kernels.items(), key=lambda kv: -kv[1])),
+            "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
             "frac": None if achieved is None else achieved / PEAK_F32_MFMA, "launches": len(durs),
             "avg_launch_ms": sum(durs) / len(durs) * 1e3 if durs else None,
             "flops_per_launch": sum(flops_all) / len(flops_all) if durs else 0.0, "traffic": traffic,
             "traffic_unit": "HBM bytes per 576x960x112 plane of the convolution (rocprofv3 --pmc passes committed under "
                             "profiles/: FETCH_SIZE x2 + WRITE_SIZE); algorithmic 495.9e6 B per plane; a launch over N "
-                            "planes moves N times that"}
+                            "planes moves N times that",
+            "probe_pass": probe_pass}
+
+
+def parity_sweep():
+    """what the strict 1080p tests measured against the real reference's digests for every rate point (data:
+    tests/golden/headline_pins.json, written from a GPU run of tests/test_gpu_engine.py)"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "headline_pins.json")) as f:
+            pins = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {}
+    for k, p in sorted(pins.items()):
+        out[k] = {"frames_with_bit_delta": sum(1 for d in p["dbits"] if d), "bit_deltas": [d for d in p["dbits"] if d],
+                  "max_abs_dpsnr_db": p["psnr_err"], "files_identical": p["same"], "files": p["same"] + p["diff"],
+                  "meets_bar": not any(p["dbits"]) and p["psnr_err"] < 1e-4}
+    return out
 
 
 def main():
+    t_process = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -119,21 +138,26 @@ def main():
     ap.add_argument("--q_index", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_aux", action="store_true", help="skip the auxiliary schedules measured after the timed region")
+    ap.add_argument("--aux_budget_s", type=float, default=240.0,
+                    help="wall-clock budget of the OPTIONAL legs after the timed region (roofline pass and cpu_baseline are "
+                         "not optional); a leg only starts while the budget lasts")
     ap.add_argument("--schedule", choices=("pairs", "stages"), default="pairs",
-                    help="what `value` times.  pairs (default): the reference harness's schedule, one encode_one_stage "
-                         "call per frame pair.  stages: the pairs of each temporal stage as one batch "
-                         "(encode_stage_pairs): same files and bits, larger launches.")
+                    help="what `value` times.  pairs (default): the reference harness's loop, one encode_one_stage call per "
+                         "frame pair, bit counts looked at after every call.  stages: the pairs of each temporal stage as "
+                         "one batch (encode_stage_pairs): same files and bits, larger launches.")
     ap.add_argument("--aux_precisions", default="bf16x3,bf16x2,bf16",
                     help="auxiliary reduced-precision profiles measured after the exact run ('' to skip)")
     ap.add_argument("--cross_gops", type=int, default=4, help="K of the auxiliary cross-GOP stage-batched figure")
     ap.add_argument("--inflight", type=int, default=1,
                     help="closed GOPs coded concurrently on this GPU (one host thread + HIP stream each; a step is then "
-                         "`inflight` GOPs).  1 keeps the per-kernel event timing of the roofline probe undisturbed.")
+                         "`inflight` GOPs).")
     ap.add_argument("--shard", choices=("gops", "pairs"), default="gops",
-                    help="gops: every rank codes its own GOP (weak scaling, no data-path collective; the default the "
-                         "driver measures).  pairs: ONE GOP, the pairs of each temporal stage spread over the ranks, "
-                         "motion context relayed rank to rank, one all-gather of the subband tree per stage (strong "
-                         "scaling, <= 4x by the 4-stage critical path).")
+                    help="what `value` times with N > 1.  gops: every rank codes its own GOP (weak scaling, no data-path "
+                         "collective; the pair-sharded layout is then timed as the `pair_sharded` block).  pairs: ONE GOP, "
+                         "the pairs of each temporal stage spread over the ranks (strong scaling).")
+    ap.add_argument("--pair_shard_steps", type=int, default=2, help="steps of the `pair_sharded` block (N > 1; 0 to skip)")
+    ap.add_argument("--overlap_gops", type=int, default=2,
+                    help="closed GOPs in flight in the `pair_sharded` block's overlapped variant (SURVEY 8e)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -219,29 +243,31 @@ def main():
         for t in workers:
             t.join()
 
-    def sync():
+    def sync(collective=True):
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None and collective:
             dist.barrier()
 
-    def timed(fn, steps, warmup):
-        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; the dominant convolution's launches
-        inside the timed region are bracketed by HIP events on the launch stream"""
+    def timed(fn, steps, warmup, probe_kernels=False, collective=True):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; convolutions of the dominant shape
+        that go through stream launches inside the timed region are bracketed by HIP events on the launch stream"""
         for _ in range(warmup):
             fn()
-        sync()
+        sync(collective)
         probe = {"match": dominant, "events": []}
+        if probe_kernels:
+            probe["kernels"] = {}
         ops.CONV_PROBE = probe
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
-        sync()
+        sync(collective)
         elapsed = time.perf_counter() - t0
         ops.CONV_PROBE = None
-        return elapsed, probe["events"]
+        return elapsed, probe
 
     with torch.no_grad():
-        elapsed, events = timed(step, args.steps, args.warmup)
+        elapsed, _ = timed(step, args.steps, args.warmup)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,28 +275,66 @@ def main():
 
     frames_total = args.gop * args.steps * (world if args.shard == "gops" else 1) * args.inflight
     value = frames_total / elapsed
-    traffic = None      # HBM bytes per plane of this kernel from the committed rocprofv3 --pmc passes (profiles/)
-    for name in ("round2_dominant_kernel.json", "round1_dominant_kernel.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
-            break
-        except (OSError, KeyError, ValueError):
-            pass
-    kname = {"pairs": "3x3 112->112 conv on 576x960 luma subband planes (N per launch = pairs coded together): "
-                      "conv3x3s1_wave_kernel<7,2> for the rows that fill whole rounds of workgroups + "
-                      "conv_mfma_pipe_kernel<7,1,1,6> for the remainder",
-             "stages": "conv3x3s1_wave_kernel<7,2> (3x3 112->112 on 576x960 subband planes, batch = pairs of the stage)"}
-    roofline = roofline_of(events, kname[args.schedule] + ", f32 MFMA 16x16x4", traffic)
-    sched_text = {"pairs": "encode_one_stage called pair by pair, the reference harness's loop (test_pMCTF_flex.py:214-223); "
-                           "results are deferred and the pairs of a temporal stage coded as one batch inside the model "
-                           "(pMCTF.hip.deferred)" if net.lazy_stages else
-                           "encode_one_stage pair by pair, eager (the reference harness's loop, test_pMCTF_flex.py:214-223)",
+    eng = net.engine()
+    plans_on = eng.use_graphs and not net.lazy_stages
+    sched_text = {"pairs": "the reference harness's loop (test_pMCTF_flex.py:196-258): encode_one_stage pair by pair, the bit "
+                           "counts of every pair looked at (its two f-strings, :240,:248) before the next call"
+                           + ("; each call replays a captured launch plan (HIP graphs), luma / chroma coders on two streams"
+                              if plans_on else "; stream launches") +
+                           ("; results DEFERRED (PMCTF_LAZY=1)" if net.lazy_stages else ""),
                   "stages": "all pairs of a temporal stage as one batch (encode_stage_pairs)"}
+
+    # ---- the north-star multi-GPU layout over the same ranks (N > 1): pairs of ONE GOP spread over the GPUs
+    pair_sharded = None
+    if world > 1 and args.shard == "gops" and args.pair_shard_steps > 0:
+        import pmctf_dist
+        frames0 = frames if rank == 0 else gop_frames(1234)       # every rank reads the same GOP (rank 0's)
+        stats = {}
+
+        def sharded():
+            last["ps"] = pmctf_dist.encode_gop_pair_sharded(net, frames0, H, W, args.q_index, tmp, rank, world, dist,
+                                                            stats=stats)
+        blocks = {}
+        try:
+            with torch.no_grad():
+                t_ps, _ = timed(sharded, args.pair_shard_steps, 1)
+            tt = torch.tensor([t_ps], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_ps = float(tt.item())
+            pair_sharded = {"value": args.gop * args.pair_shard_steps / t_ps, "unit": "frames/s", "scaling": "strong",
+                            "ms_per_step": t_ps / args.pair_shard_steps * 1e3, "steps": args.pair_shard_steps,
+                            "speedup_vs_one_gpu_coding_this_gop": (elapsed / args.steps) / (t_ps / args.pair_shard_steps),
+                            "gather_bytes_per_stage": stats.get("gather_bytes_per_stage"),
+                            "relay_hops": stats.get("relay_hops"), "relay_bytes_per_hop": stats.get("relay_bytes_per_hop"),
+                            "collective": "all_gather_into_tensor (RCCL)" if dist.get_backend() == "nccl" else "all_gather (gloo)",
+                            "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
+                                        "rank, one all-gather of the subband tree per stage",
+                            "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
+            if args.overlap_gops > 1 and hasattr(pmctf_dist, "encode_gops_pair_sharded_overlapped"):
+                G2 = args.overlap_gops
+                gops = [frames0] + [gop_frames(1234 + 1000 * k) for k in range(1, G2)]
+                folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_o{k}_") for k in range(1, G2)]
+
+                def overlapped():
+                    last["po"] = pmctf_dist.encode_gops_pair_sharded_overlapped(net, gops, H, W, args.q_index, folders,
+                                                                                rank, world, dist)
+                with torch.no_grad():
+                    t_po, _ = timed(overlapped, max(1, args.pair_shard_steps // 2), 1)
+                tt = torch.tensor([t_po], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                n_po = max(1, args.pair_shard_steps // 2)
+                pair_sharded["overlapped_gops"] = {
+                    "gops_in_flight": G2, "value": G2 * args.gop * n_po / float(tt.item()), "unit": "frames/s",
+                    "ms_per_step": float(tt.item()) / n_po * 1e3, "steps": n_po,
+                    "schedule": f"{G2} closed GOPs interleaved: ranks idle in the late stages of one GOP code the early stages "
+                                f"of the next (SURVEY 8e)",
+                    "bits_identical_to_rank0_gop": (last["po"][0]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
+        except Exception as e:  # noqa: BLE001 - an auxiliary block must never cost the headline line
+            pair_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         enc = last["enc"]
-        rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+        rec = pmctf_gop.decode_gop(net, [list(f) for f in enc["frames_coded"]])
         ps = pmctf_gop.gop_psnr(rec, frames, H, W)
         headline = (W, H, args.gop, args.q_index) == (1920, 1080, 16, 3)
         out = {
@@ -288,10 +352,11 @@ def main():
                        "frames_per_step": args.gop * args.inflight, "gops_in_flight_per_gpu": args.inflight,
                        "parallelism": f"gop-dp{world}" if args.shard == "gops" else f"pair-shard{world}",
                        "weights": "deterministic synthetic (pmctf_synth seed 0)"},
-            "roofline": roofline,
             "bpp": sum(enc["bits"]) / (args.gop * W * H),
             "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
         }
+        if pair_sharded is not None:
+            out["pair_sharded"] = pair_sharded
         # "+ bpp/PSNR parity vs CPU ref" of BASELINE's metric: rank 0 codes exactly the sequence the real reference was
         # run on (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4 [--q_index q]);
         # compare with the digests of that run (data, tests/golden/).
@@ -307,7 +372,18 @@ def main():
                 "psnr_yuv_reference": float(g["gop.psnr_yuv"].mean()),
                 "psnr_max_abs_err_db": float(max(abs(p["yuv"] - r) for p, r in zip(ps, g["gop.psnr_yuv"].tolist()))),
             }
+        if headline:
+            out["parity_sweep"] = parity_sweep()
         del rec
+        traffic = None      # HBM bytes per plane of this kernel from the committed rocprofv3 --pmc passes (profiles/)
+        for name in ("round3_dominant_kernel.json", "round2_dominant_kernel.json", "round1_dominant_kernel.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
+                break
+            except (OSError, KeyError, ValueError):
+                pass
+
         def leg(name, fn):
             """An auxiliary figure must never cost the headline line: a failing leg is recorded and skipped."""
             try:
@@ -316,50 +392,80 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out.setdefault("aux_errors", {})[name] = f"{type(e).__name__}: {e}"[:300]
 
-        aux = world == 1 and args.inflight == 1 and not args.no_aux
-        aux_steps = max(1, min(args.steps, 5))
-        if aux and args.schedule == "pairs" and net.lazy_stages:
-            def eager():
-                # the same harness loop with every result looked at immediately (PMCTF_LAZY=0): call-by-call coding
-                net.lazy_stages = False
-                try:
-                    t_e, ev_e = timed(step_main, aux_steps, 1)
-                finally:
-                    net.lazy_stages = True
-                out["eager_pair_by_pair"] = {
-                    "value": args.gop * aux_steps / t_e, "unit": "frames/s", "ms_per_step": t_e / aux_steps * 1e3,
-                    "steps": aux_steps, "schedule": "encode_one_stage pair by pair, every call finished before it returns",
-                    "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"],
-                    "roofline": roofline_of(ev_e, kname["pairs"] + ", f32 MFMA 16x16x4", traffic)}
-            leg("eager_pair_by_pair", eager)
+        aux_steps = max(1, min(args.steps, 3))
+        single = world == 1 and args.inflight == 1
 
-            def two_streams():
-                # luma and chroma coders of a stage on two HIP streams (independent once the motion is known): the
-                # small launches of one fill the tails of the other.  Off in the headline run because kernels that
-                # share the GPU spoil per-kernel event timing (the roofline probe).
-                eng = net.engine()
-                keep = (eng.multi_stream, eng.multi_stream_max_pairs)
-                eng.multi_stream, eng.multi_stream_max_pairs = True, 1 << 20
+        # ---- not optional: the roofline pass (plans off, one stream: per-kernel events mean something) -------------------
+        def roofline_pass():
+            keep = eng.use_graphs
+            eng.use_graphs = False
+            try:
+                gop_alone = lambda: last.__setitem__("enc", pmctf_gop.encode_gop(net, frames, H, W, args.q_index, tmp))
+                t_s, pr = timed(gop_alone if world > 1 else step_main, aux_steps, 0, probe_kernels=True, collective=False)
+            finally:
+                eng.use_graphs = keep
+            out["roofline"] = roofline_of(
+                pr["events"], pr["kernels"], traffic,
+                "separate pass of the same GOPs through stream launches on ONE stream, right after the timed region: in the "
+                "timed region the launches are replayed from HIP graphs with luma and chroma kernels sharing the GPU, which "
+                "per-kernel events cannot separate" if plans_on and args.schedule == "pairs" else
+                "the timed schedule, stream launches")
+            out["stream_launches_single_stream"] = {
+                "value": args.gop * aux_steps / t_s, "unit": "frames/s", "ms_per_step": t_s / aux_steps * 1e3, "steps": aux_steps,
+                "schedule": "the harness loop, every launch issued from the host on one stream (captured launch plans off)",
+                "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"]}
+        if world == 1 or rank == 0:
+            leg("roofline", roofline_pass)
+        if "roofline" not in out:
+            out["roofline"] = roofline_of([], {}, traffic, "failed")
+
+        # ---- not optional: the CPU baseline -------------------------------------------------------------------------------
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, H, args.gop, args.q_index)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed",
+                                       "error": f"{type(e).__name__}: {e}"[:300]}
+
+        # ---- optional legs, while the budget lasts ------------------------------------------------------------------------
+        t_aux = time.time()
+        skipped = []
+
+        def optional(name, fn):
+            if time.time() - t_aux > args.aux_budget_s:
+                skipped.append(name)
+                return
+            leg(name, fn)
+
+        aux = single and not args.no_aux
+        if aux and args.schedule == "pairs" and not net.lazy_stages:
+            def deferred():
+                net.lazy_stages = True
                 try:
-                    t_m, _ = timed(step_main, aux_steps, 1)
+                    def run():
+                        last["enc"] = pmctf_gop.encode_gop(net, frames, H, W, args.q_index, tmp, store_only=True)
+                    t_d, _ = timed(run, aux_steps, 1)
                 finally:
-                    eng.multi_stream, eng.multi_stream_max_pairs = keep
-                out["luma_chroma_two_streams"] = {
-                    "value": args.gop * aux_steps / t_m, "unit": "frames/s", "ms_per_step": t_m / aux_steps * 1e3,
-                    "steps": aux_steps, "schedule": sched_text["pairs"] + "; luma / chroma coders on two HIP streams",
+                    net.lazy_stages = False
+                out["deferred_store_only"] = {
+                    "value": args.gop * aux_steps / t_d, "unit": "frames/s", "ms_per_step": t_d / aux_steps * 1e3,
+                    "steps": aux_steps,
+                    "schedule": "the harness loop WITHOUT its two per-pair prints (a caller that only stores the results), "
+                                "model with lazy_stages=True: the pairs of a temporal stage coded as one batch when the next "
+                                "stage needs them (pMCTF.hip.deferred)",
                     "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"]}
-            leg("luma_chroma_two_streams", two_streams)
+            optional("deferred_store_only", deferred)
         if aux and args.schedule == "pairs":
             def stage_batched():
                 def batched():
                     last["enc"] = pmctf_gop.encode_gop_batched(net, frames, H, W, args.q_index, tmp)
-                t_b, ev_b = timed(batched, aux_steps, 1)
+                t_b, pr = timed(batched, aux_steps, 1, probe_kernels=True)
                 out["stage_batched"] = {
                     "value": args.gop * aux_steps / t_b, "unit": "frames/s", "ms_per_step": t_b / aux_steps * 1e3,
                     "steps": aux_steps, "schedule": sched_text["stages"],
                     "bits_identical_to_headline": last["enc"]["bits"] == enc["bits"],
-                    "roofline": roofline_of(ev_b, kname["stages"] + ", f32 MFMA 16x16x4", traffic)}
-            leg("stage_batched", stage_batched)
+                    "roofline": roofline_of(pr["events"], pr["kernels"], traffic, "this leg's own timed region (stream launches)")}
+            optional("stage_batched", stage_batched)
         K = args.cross_gops
         if aux and K > 1 and hasattr(pmctf_gop, "encode_gops_batched"):
             def cross_gop():
@@ -370,16 +476,34 @@ def main():
                     last["encs"] = pmctf_gop.encode_gops_batched(net, gops, H, W, args.q_index, folders)
                 k_steps = max(1, min(args.steps, 2))
                 try:
-                    t_x, ev_x = timed(cross, k_steps, 1)
+                    t_x, pr = timed(cross, k_steps, 1, probe_kernels=True)
                     out["cross_gop_batched"] = {
                         "value": K * args.gop * k_steps / t_x, "unit": "frames/s", "ms_per_step": t_x / k_steps * 1e3,
                         "steps": k_steps, "gops_per_step": K, "frames_per_step": K * args.gop,
                         "schedule": f"stage s of {K} closed GOPs as one batch (pmctf_gop.encode_gops_batched)",
                         "bits_identical_to_headline": last["encs"][0]["bits"] == enc["bits"],
-                        "roofline": roofline_of(ev_x, kname["stages"] + ", f32 MFMA 16x16x4", traffic)}
+                        "roofline": roofline_of(pr["events"], pr["kernels"], traffic, "this leg's own timed region (stream launches)")}
                 finally:
                     last.pop("encs", None)
-            leg("cross_gop_batched", cross_gop)
+            optional("cross_gop_batched", cross_gop)
+        if aux:
+            def decode_pair():
+                # the real decoder (skip_decoding=False, the harness's default: test_pMCTF_flex.py:53): one H pair and the
+                # pair that also codes L, decoded from the files just written (pMCTF_L.py:594-612)
+                dpb0 = {"mv_feature": None, "ref_mv_y": None}
+                res = {}
+                for name, code_lt in (("h_pair", False), ("h_and_l_pair", True)):
+                    ts = []
+                    for _ in range(2):
+                        r = net.encode_one_stage(frames[0], frames[1], code_lt, dpb0, output_path=os.path.join(tmp, "1.bin"),
+                                                 pic_width=W, pic_height=H, skip_decoding=False, stage_idx=0,
+                                                 q_index=args.q_index)
+                        ts.append(r["decoding_time"])
+                    res[name] = {"decoding_time_s": min(ts), "encoding_time_s": r["encoding_time"]}
+                out["decode_pair"] = dict(res, unit="s per 1080p pair (motion + luma + chroma streams, files read back)",
+                                          schedule="encode_one_stage(skip_decoding=False): decompress_mv + decompress_one_stage "
+                                                   "of luma and chroma; the sequential LL subband decodes inside one persistent kernel")
+            optional("decode_pair", decode_pair)
         if aux and args.aux_precisions:
             # AUXILIARY arithmetic profiles (second conv variant): the dense 3x3 convolutions on bf16 MFMA
             # with operands split into 3 / 2 / 1 planes.  Reported beside the exact figure, never instead of it, with what
@@ -393,18 +517,18 @@ def main():
 
             def profile(prec):
                 net.precision = prec
-                k_p = max(1, min(args.steps, 3))
-                t_p, ev_p = timed(step_main, k_p, 1)
+                k_p = max(1, min(args.steps, 2))
+                t_p, _ = timed(step_main, k_p, 1)
                 e_p = last["enc"]
-                ps_p = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, e_p["frames_coded"]), frames, H, W)
+                ps_p = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, [list(f) for f in e_p["frames_coded"]]), frames, H, W)
                 blk = {"value": args.gop * k_p / t_p, "unit": "frames/s", "ms_per_step": t_p / k_p * 1e3, "steps": k_p,
                        "dtype": {"bf16x3": "bf16 x3 split operands, f32 accumulate", "bf16x2": "bf16 x2 split, f32 accumulate",
                                  "bf16": "bf16, f32 accumulate"}.get(prec, prec),
                        "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px (conv_split.hip); all else exact f32",
+                       "schedule": sched_text[args.schedule],
                        "bpp": sum(e_p["bits"]) / (args.gop * W * H), "psnr_yuv": sum(p["yuv"] for p in ps_p) / len(ps_p),
                        "rel_bits_vs_exact_profile": (sum(e_p["bits"]) - sum(enc["bits"])) / sum(enc["bits"]),
-                       "max_abs_dpsnr_vs_exact_profile_db": max(abs(p["yuv"] - q["yuv"]) for p, q in zip(ps_p, ps)),
-                       "dominant_conv_tflops_equivalent": roofline_of(ev_p, "", None)["achieved"]}
+                       "max_abs_dpsnr_vs_exact_profile_db": max(abs(p["yuv"] - q["yuv"]) for p, q in zip(ps_p, ps))}
                 if ref_bits is not None:
                     db = np.array(e_p["bits"]) - ref_bits
                     blk["vs_reference_cpu"] = {"frames_with_identical_bits": int((db == 0).sum()), "frames": int(db.size),
@@ -413,15 +537,11 @@ def main():
                                                "max_abs_dpsnr_db": float(np.abs(np.array([p["yuv"] for p in ps_p]) - ref_psnr).max())}
                 out["aux_profiles"][prec] = blk
             for prec in args.aux_precisions.split(","):
-                leg("aux_profiles." + prec, lambda prec=prec: profile(prec))
+                optional("aux_profiles." + prec, lambda prec=prec: profile(prec))
             net.precision = "f32"
-            leg("restore_f32_engine", net.engine)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(W, H, args.gop, args.q_index)
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed",
-                                       "error": f"{type(e).__name__}: {e}"[:300]}
+        if skipped:
+            out["aux_skipped_over_budget"] = skipped
+        out["bench_wall_s"] = time.time() - t_process
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -57,6 +57,10 @@ int64_t pmctf_conv2d_packed_bias_size(int Cout);
  * wave-private kernel with one cout tile per workgroup on cout-split 3x3 planes that fill the waves' 4x16 tiles to >= 90 %.
  * Environment only: PMCTF_FEWCOUT_LDS=0 / PMCTF_DWCONV_COLUMN=0 select the older one/two-cout and depthwise kernels. */
 int pmctf_conv2d_set_option(const char *name, long value);
+/* Measurement aid (no reference counterpart): which kernel(s) the LAST pmctf_conv2d_nhwc[_geom]_f32 call of the calling
+ * thread launched — kernel expression, tile parameters and grid, several joined by " + " when the launch was cut
+ * (whole rounds of workgroups + remainder).  bench.py names the kernel behind its roofline figure from this. */
+int pmctf_conv2d_last_launch(char *buf, int capacity);
 
 /* nn.Conv2d forward (groups=1, zero padding), optionally fused with what follows it
  * in the reference: y = act(conv(x) + bias) [+ res1] [+ res2].

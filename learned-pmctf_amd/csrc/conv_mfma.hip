@@ -1434,6 +1434,22 @@ inline bool wave_eligible(const ConvArgs &a) {
 }
 
 // One launch over output rows [r0, r1) with MT cout tiles per workgroup (gz = cout-tile groups in grid.z).
+// What the last convolution call of this thread launched (kernel expression, tile parameters, grid): bench.py reports the
+// kernel behind its roofline figure from here instead of from a string literal.
+thread_local char g_last_launch[512];
+thread_local int g_last_len = 0;
+void note_launch(const char *kernel, int mt, int nt, int tw16, dim3 g) {
+    if (g_last_len >= (int)sizeof(g_last_launch) - 1) return;
+    const int n = snprintf(g_last_launch + g_last_len, sizeof(g_last_launch) - (size_t)g_last_len,
+                           "%s%s [MT=%d NT=%d TW16=%d] grid %ux%ux%u", g_last_len ? " + " : "", kernel, mt, nt, tw16, g.x, g.y, g.z);
+    if (n > 0) g_last_len = g_last_len + n < (int)sizeof(g_last_launch) ? g_last_len + n : (int)sizeof(g_last_launch) - 1;
+}
+#define CONV_LAUNCH(kernel, grid, block, smem, stream, ...)          \
+    do {                                                             \
+        note_launch(#kernel, MT, NT, TW16, grid);                    \
+        PM_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__);   \
+    } while (0)
+
 template <int MT, int NT, int TW16>
 int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     constexpr int TW = TW16 * 16;
@@ -1455,20 +1471,20 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
                              (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32);
             if constexpr (MT <= 4) {
                 if (knob("NBUF1") != 0) {       // narrow layers: single patch buffer, three workgroups per CU
-                    if (k33) PM_LAUNCH((conv3x3s1_wave_kernel<MT, 1>), grid, dim3(256), wsmem / 2, st, b);
-                    else PM_LAUNCH((conv_mfma_wave_kernel<MT, 7, 1>), grid, dim3(256), wsmem / 2, st, b);
+                    if (k33) CONV_LAUNCH((conv3x3s1_wave_kernel<MT, 1>), grid, dim3(256), wsmem / 2, st, b);
+                    else CONV_LAUNCH((conv_mfma_wave_kernel<MT, 7, 1>), grid, dim3(256), wsmem / 2, st, b);
                     return pm_launch_status();
                 }
             }
             if (k33) {
                 static std::once_flag once_k;
                 allow_big_lds(conv3x3s1_wave_kernel<MT, 2>, once_k);
-                PM_LAUNCH((conv3x3s1_wave_kernel<MT, 2>), grid, dim3(256), wsmem, st, b);
+                CONV_LAUNCH((conv3x3s1_wave_kernel<MT, 2>), grid, dim3(256), wsmem, st, b);
                 return pm_launch_status();
             }
             static std::once_flag once_w;
             allow_big_lds(conv_mfma_wave_kernel<MT, 7>, once_w);
-            PM_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
+            CONV_LAUNCH((conv_mfma_wave_kernel<MT, 7>), grid, dim3(256), wsmem, st, b);
             return pm_launch_status();
         }
     }
@@ -1477,7 +1493,7 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
             (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
             static std::once_flag once_7;
             allow_big_lds(conv7x7s1_pipe_kernel<MT, NT>, once_7);
-            PM_LAUNCH((conv7x7s1_pipe_kernel<MT, NT>), grid, dim3(256), 2 * smem, st, b);
+            CONV_LAUNCH((conv7x7s1_pipe_kernel<MT, NT>), grid, dim3(256), 2 * smem, st, b);
             return pm_launch_status();
         }
     }
@@ -1492,29 +1508,29 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
             if constexpr (NT == 1 && TW16 == 1) {
                 if (a.KH == 3 && a.KW == 3 && a.S == 1 && knob("K33") != 0 &&
                     (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
-                    PM_LAUNCH((conv3x3s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
+                    CONV_LAUNCH((conv3x3s1_pipe_kernel<MT>), grid, dim3(256), 2 * smem, st, b);
                     return pm_launch_status();
                 }
                 if (a.KH == 3 && a.KW == 3 && a.S == 2 && knob("K33") != 0 &&
                     (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
-                    PM_LAUNCH((conv3x3s1_pipe_kernel<MT, 2>), grid, dim3(256), 2 * smem, st, b);
+                    CONV_LAUNCH((conv3x3s1_pipe_kernel<MT, 2>), grid, dim3(256), 2 * smem, st, b);
                     return pm_launch_status();
                 }
             }
             static std::once_flag once_p6, once_p9;
             if (slots <= 6) {
                 allow_big_lds(conv_mfma_pipe_kernel<MT, NT, TW16, 6>, once_p6);
-                PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 6>), grid, dim3(256), 2 * smem, st, b);
+                CONV_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 6>), grid, dim3(256), 2 * smem, st, b);
             } else {
                 allow_big_lds(conv_mfma_pipe_kernel<MT, NT, TW16, 9>, once_p9);
-                PM_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 9>), grid, dim3(256), 2 * smem, st, b);
+                CONV_LAUNCH((conv_mfma_pipe_kernel<MT, NT, TW16, 9>), grid, dim3(256), 2 * smem, st, b);
             }
             return pm_launch_status();
         }
     }
     static std::once_flag once_s;
     allow_big_lds(conv_mfma_kernel<MT, NT, TW16>, once_s);
-    PM_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
+    CONV_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
     return pm_launch_status();
 }
 
@@ -1530,6 +1546,7 @@ int launch_res(const ConvArgs &a, int gz, hipStream_t st) {
     const size_t smem = (size_t)LH * LW * (a.Cin + 2) * sizeof(float);
     if ((a.Cin % CB) != 0 || smem > 52 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
+    note_launch("conv_mfma_res_kernel<MT>", MT, 1, 1, grid);
     PM_LAUNCH((conv_mfma_res_kernel<MT>), grid, dim3(256), smem, st, b);
     return pm_launch_status();
 }
@@ -1556,6 +1573,7 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
                 const long cap = knob("C16_WGS");
                 if (wgs > cap) wgs = cap;
                 const size_t smem = (size_t)6 * 18 * CP * sizeof(float) * 2 * WAVES;
+                note_launch("conv16_persistent_kernel", 1, 1, 1, dim3((unsigned)wgs));
                 PM_LAUNCH(conv16_persistent_kernel, dim3((unsigned)wgs), dim3(256), smem, st, b, (int)tiles);
                 return pm_launch_status();
             }
@@ -1637,6 +1655,7 @@ int launch_1x1_t(const ConvArgs &a, long P, int tiles, hipStream_t st) {
     const int gy = (tiles + WAVES * MTW - 1) / (WAVES * MTW);
     if (gx > 0x7fffffffL) return PMCTF_EINVAL;
     const size_t smem = (size_t)2 * PX * 66 * sizeof(float);
+    note_launch("conv1x1_kernel<MTW, NT>", MTW, NT, 1, dim3((unsigned)gx, gy));
     PM_LAUNCH((conv1x1_kernel<MTW, NT>), dim3((unsigned)gx, gy), dim3(256), smem, st, a, P, tiles);
     return pm_launch_status();
 }
@@ -1727,6 +1746,8 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;
+    g_last_len = 0;
+    g_last_launch[0] = 0;
     if (KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
         knob("K11") != 0 && MT * MB >= knob("K11_MIN_TILES")) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
         a.mtp = MT;
@@ -1739,6 +1760,12 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     case 7: return dispatch_tile<7>(a, MB, st);
     default: return dispatch_tile<8>(a, MB, st);
     }
+}
+
+extern "C" int pmctf_conv2d_last_launch(char *buf, int capacity) {
+    if (!buf || capacity <= 0) return PMCTF_EINVAL;
+    snprintf(buf, (size_t)capacity, "%s", g_last_launch);
+    return PMCTF_OK;
 }
 
 extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const float *bp, const float *res1,

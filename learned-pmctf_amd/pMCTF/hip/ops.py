@@ -128,6 +128,10 @@ class Conv2d:
         if probe is not None:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))
+            if "kernels" in probe and not (self.split and N * H * W >= SPLIT_MIN_PX):
+                buf = C.create_string_buffer(512)
+                L.pmctf_conv2d_last_launch(buf, 512)
+                probe["kernels"][buf.value.decode()] = probe["kernels"].get(buf.value.decode(), 0) + 1
         return y
 
 

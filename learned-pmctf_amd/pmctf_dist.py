@@ -43,8 +43,13 @@ def gather_gop_metrics(local, n_gops, gop, dist=None, device="cpu"):
 # Results are identical to pmctf_gop.encode_gop on one device.  On the GPU node the backend is "nccl" (= RCCL over xGMI:
 # device tensors, all_gather_into_tensor); under "gloo" (CPU tests, one-GPU rehearsal) records are staged through host
 # memory.
-def pair_owner(pair_idx, world):
-    return pair_idx % world
+def pair_owner(pair_idx, world, gop_idx=0):
+    """rank that codes pair `pair_idx` of a stage.  Closed GOPs coded together (encode_gops_pair_sharded_overlapped) run
+    their chains in opposite directions with a shifted start — GOP 0: pair k on rank k, GOP 1: pair k on rank N-1-k,
+    GOP 2: pair k on rank k + N/2, ... — so that the late stages of the GOPs (4, 2, 1 pairs) land on different ranks."""
+    shift = (gop_idx // 2) * max(1, world // 2)
+    k = (pair_idx + shift) % world
+    return k if gop_idx % 2 == 0 else world - 1 - k
 
 
 def _is_nccl(dist):
@@ -52,23 +57,29 @@ def _is_nccl(dist):
 
 
 class _Relay:
-    """Hands the motion codec's context from the owner of pair k-1 to the owner of pair k (point-to-point)."""
+    """Hands the motion codec's context from the owner of pair k-1 to the owner of pair k (point-to-point).  The two
+    receive buffers are allocated once: a rank consumes a context (the motion codec copies it into its own storage)
+    before it asks for the next one."""
 
     def __init__(self, dist, rank, world, device, shapes):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
         self.shapes = shapes                     # logical NCHW shapes of (mv_feature, ref_mv_y)
         self.pending = []
         self.comm_dev = device if _is_nccl(dist) else "cpu"
+        self.bufs = [torch.empty((n, h, w, c), dtype=torch.float32, device=self.comm_dev)      # channels-last storage
+                     for (n, c, h, w) in shapes]
+        self.hops = 0
+        self.bytes_per_hop = sum(4 * b.numel() for b in self.bufs)
 
     def recv(self, src):
         out = {}
-        for key, (n, c, h, w) in zip(("mv_feature", "ref_mv_y"), self.shapes):
-            buf = torch.empty((n, h, w, c), dtype=torch.float32, device=self.comm_dev)   # channels-last storage
+        for key, buf in zip(("mv_feature", "ref_mv_y"), self.bufs):
             self.dist.recv(buf, src=src)
             out[key] = buf.to(self.device).permute(0, 3, 1, 2)
         return out
 
     def send(self, dpb, dst):
+        self.hops += 1
         for key in ("mv_feature", "ref_mv_y"):
             t = dpb[key].permute(0, 2, 3, 1).contiguous().to(self.comm_dev)
             self.pending.append((self.dist.isend(t, dst=dst), t))
@@ -92,96 +103,139 @@ def _record_layout(shapes):
     return offs, o, o + 24
 
 
+class PairShardWorkspace:
+    """The gather buffers of encode_gop[s]_pair_sharded, allocated ONCE and reused GOP after GOP (a caller that codes a
+    sequence passes the same workspace to every call; without one, every call allocates its own).  frames_coded of a
+    call are views of these buffers: they are valid until the next call that uses the workspace."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, key, shape, device):
+        t = self.bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != torch.device(device):
+            t = self.bufs[key] = torch.empty(shape, dtype=torch.uint8, device=device)
+        return t
+
+
 def encode_gop_pair_sharded(codec, frames, pic_height, pic_width, q_index, bin_folder, rank=0, world=1, dist=None,
-                            psize=128):
+                            psize=128, stats=None, workspace=None):
     """Same schedule and same return value as pmctf_gop.encode_gop (bits, bits_mv, frames_coded; `results` holds only
     this rank's pairs), with the pairs of every stage spread over the ranks.  Every rank ends up with the complete
     subband tree (frames_coded), so any of them can run pmctf_gop.decode_gop.
 
     The codec needs, beyond the reference API: `dpb_shapes(height, width)` and the keyword arguments `dpb` (may be a
     callable, evaluated once the motion has been estimated) and `on_dpb` (called with the new context as soon as the
-    motion codec has produced it) of encode_one_stage."""
+    motion codec has produced it) of encode_one_stage.
+    stats: dict that receives gather_bytes_per_stage, relay_hops, relay_bytes_per_hop of this rank."""
+    return encode_gops_pair_sharded_overlapped(codec, [frames], pic_height, pic_width, q_index, [bin_folder], rank, world,
+                                               dist, psize, stats, workspace)[0]
+
+
+def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_index, bin_folders, rank=0, world=1,
+                                        dist=None, psize=128, stats=None, workspace=None):
+    """Several closed GOPs in flight over the same ranks (SURVEY 8e's GOP overlap): stage s of ALL of them is coded before
+    stage s+1 of any, the chains of consecutive GOPs run in opposite directions (pair_owner), so the ranks one GOP leaves
+    idle in its late stages (4, 2, 1 pairs) code the other's.  With 8 ranks and two GOP-16s the critical path is
+    2 + 1 + 1 + 1 pair-times for 32 frames instead of 2 x 4.  Per GOP-stage: one relay chain and ONE all-gather, exactly as
+    in encode_gop_pair_sharded; a rank works through its pairs of a stage in the order of their position in their chain
+    (lowest first, which keeps the two chains moving from both ends and cannot deadlock: every wait is for a pair with a
+    lower position).  Returns one encode_gop-style dict per GOP, identical to coding them one after the other."""
     import math
     import os
-    gop = len(frames)
+    G = len(gops)
+    gop = len(gops[0])
     stages = int(round(math.log2(gop)))
-    assert 2 ** stages == gop and gop >= 2
-    device = frames[0][0].device
+    assert 2 ** stages == gop and gop >= 2 and all(len(g) == gop for g in gops) and len(bin_folders) == G
+    if world > 1 and dist is None:
+        raise ValueError("pair sharding over world > 1 ranks needs an initialised torch.distributed")
+    device = gops[0][0][0].device
     multi = dist is not None and world > 1
-    y0, c0 = frames[0]
+    y0, c0 = gops[0][0]
     shapes = [tuple(y0.shape), tuple(c0.shape), tuple(y0.shape), tuple(c0.shape), (1, 2) + tuple(y0.shape[2:])]
     offs, sc_off, rec_bytes = _record_layout(shapes)
     relay = _Relay(dist, rank, world, device, codec.dpb_shapes(y0.shape[2], y0.shape[3])) if multi else None
-    frames_coded = [None] * gop
-    bits = [None] * gop
-    bits_mv = [None] * gop
-    results = []
+    ws = workspace if workspace is not None else PairShardWorkspace()
+    outs = [{"bits": [None] * gop, "bits_mv": [None] * gop, "frames_coded": [None] * gop, "results": [],
+             "stages": stages} for _ in range(G)]
+    gather_bytes = []
     num_frames = gop
+    comm_dev = device if (not multi or _is_nccl(dist)) else "cpu"
     for stage_idx in range(stages):
         num_frames //= 2
         step = 2 ** stage_idx
         code_lt = (stage_idx + 1) == stages
         me_num = min(codec.num_me_stages - 1, stage_idx)
         slots = (num_frames + world - 1) // world
-        comm_dev = device if (not multi or _is_nccl(dist)) else "cpu"
-        mine_buf = torch.empty((slots, rec_bytes), dtype=torch.uint8, device=device)
-        last_dpb = {"mv_feature": None, "ref_mv_y": None}
-        for p in range(rank, num_frames, world):
+        mine = [ws.get(("mine", j, stage_idx), (slots, rec_bytes), device) for j in range(G)]
+        last_dpb = [{"mv_feature": None, "ref_mv_y": None} for _ in range(G)]
+        # this rank's pairs of the stage, lowest chain position first
+        tasks = sorted((p, j) for j in range(G) for p in range(num_frames) if pair_owner(p, world, j) == rank)
+        for p, j in tasks:
+            o = outs[j]
             i_ref = p * 2 * step
             i_cur = i_ref + step
             if stage_idx == 0:
-                (y_ref, c_ref), (y_cur, c_cur) = frames[i_ref], frames[i_cur]
+                (y_ref, c_ref), (y_cur, c_cur) = gops[j][i_ref], gops[j][i_cur]
             else:
-                y_ref, c_ref, _ = frames_coded[i_ref]
-                y_cur, c_cur, _ = frames_coded[i_cur]
+                y_ref, c_ref, _ = o["frames_coded"][i_ref]
+                y_cur, c_cur, _ = o["frames_coded"][i_cur]
             if p == 0:
                 dpb_in = {"mv_feature": None, "ref_mv_y": None}
             elif world == 1:
-                dpb_in = last_dpb
+                dpb_in = last_dpb[j]
             else:
-                dpb_in = (lambda src=pair_owner(p - 1, world): relay.recv(src))
+                dpb_in = (lambda src=pair_owner(p - 1, world, j): relay.recv(src))
 
-            def on_dpb(d, p=p):
+            def on_dpb(d, p=p, j=j):
                 if multi and p + 1 < num_frames:
-                    relay.send(d, pair_owner(p + 1, world))
+                    relay.send(d, pair_owner(p + 1, world, j))
 
             r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur],
-                                       output_path=os.path.join(bin_folder, f"{i_cur}.bin"), pic_height=pic_height,
+                                       output_path=os.path.join(bin_folders[j], f"{i_cur}.bin"), pic_height=pic_height,
                                        pic_width=pic_width, stage_idx=me_num, code_lt=code_lt, psize=psize,
                                        skip_decoding=True, dpb=dpb_in, q_index=q_index, on_dpb=on_dpb)
-            last_dpb = r["dpb"]
-            results.append(r)
-            rec = mine_buf[p // world]
-            for (o, n), t in zip(offs, (r["L_t"], r["L_tc"], r["H_t"], r["H_tc"], r["mv_hat"])):
-                rec[o:o + 4 * n].view(torch.float32).copy_(t.reshape(-1))
+            last_dpb[j] = r["dpb"]
+            o["results"].append(r)
+            rec = mine[j][p // world]
+            for (o_, n), t in zip(offs, (r["L_t"], r["L_tc"], r["H_t"], r["H_tc"], r["mv_hat"])):
+                rec[o_:o_ + 4 * n].view(torch.float32).copy_(t.reshape(-1))
             sc = torch.tensor([float(r["bit_H"]), float(r["bit_ME"]), float(r["bit_L"]) if code_lt else 0.0],
                               dtype=torch.float64)
             rec[sc_off:sc_off + 24].copy_(sc.view(torch.uint8))
         if relay is not None:
             relay.drain()
-        # ---- the one collective of the stage
-        if multi:
-            everything = torch.empty((world, slots, rec_bytes), dtype=torch.uint8, device=comm_dev)
-            if _is_nccl(dist):
-                dist.all_gather_into_tensor(everything.view(-1), mine_buf.view(-1))
+        # ---- the one collective per GOP of the stage (same order on every rank)
+        for j in range(G):
+            o = outs[j]
+            if multi:
+                everything = ws.get(("all", j, stage_idx), (world, slots, rec_bytes), comm_dev)
+                if _is_nccl(dist):
+                    dist.all_gather_into_tensor(everything.view(-1), mine[j].view(-1))
+                else:
+                    dist.all_gather(list(everything.unbind(0)), mine[j].to(comm_dev))
+                    everything = everything.to(device)
+                gather_bytes.append(world * slots * rec_bytes)
             else:
-                dist.all_gather(list(everything.unbind(0)), mine_buf.to(comm_dev))
-                everything = everything.to(device)
-        else:
-            everything = mine_buf.unsqueeze(0)
-        scalars = everything[:, :, sc_off:sc_off + 24].contiguous().cpu().view(torch.float64)     # (world, slots, 3)
-        for p in range(num_frames):
-            i_ref = p * 2 * step
-            i_cur = i_ref + step
-            rec = everything[pair_owner(p, world), p // world]
-            L_t, L_tc, H_t, H_tc, mv_hat = [rec[o:o + 4 * n].view(torch.float32).view(shp)
-                                            for (o, n), shp in zip(offs, shapes)]
-            bit_H, bit_ME, bit_L = scalars[pair_owner(p, world), p // world].tolist()
-            frames_coded[i_ref] = [L_t, L_tc, None]
-            frames_coded[i_cur] = [H_t, H_tc, mv_hat]
-            bits[i_cur] = bit_H + bit_ME
-            bits_mv[i_cur] = bit_ME
-            if code_lt:
-                bits[i_ref] = bit_L
-                bits_mv[i_ref] = 0.0
-    return {"bits": bits, "bits_mv": bits_mv, "frames_coded": frames_coded, "results": results, "stages": stages}
+                everything = mine[j].unsqueeze(0)
+            scalars = everything[:, :, sc_off:sc_off + 24].contiguous().cpu().view(torch.float64)     # (world, slots, 3)
+            for p in range(num_frames):
+                i_ref = p * 2 * step
+                i_cur = i_ref + step
+                own = pair_owner(p, world, j)
+                rec = everything[own, p // world]
+                L_t, L_tc, H_t, H_tc, mv_hat = [rec[o_:o_ + 4 * n].view(torch.float32).view(shp)
+                                                for (o_, n), shp in zip(offs, shapes)]
+                bit_H, bit_ME, bit_L = scalars[own, p // world].tolist()
+                o["frames_coded"][i_ref] = [L_t, L_tc, None]
+                o["frames_coded"][i_cur] = [H_t, H_tc, mv_hat]
+                o["bits"][i_cur] = bit_H + bit_ME
+                o["bits_mv"][i_cur] = bit_ME
+                if code_lt:
+                    o["bits"][i_ref] = bit_L
+                    o["bits_mv"][i_ref] = 0.0
+    if stats is not None:
+        stats["gather_bytes_per_stage"] = gather_bytes
+        stats["relay_hops"] = relay.hops if relay is not None else 0
+        stats["relay_bytes_per_hop"] = relay.bytes_per_hop if relay is not None else 0
+    return outs

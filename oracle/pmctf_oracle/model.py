@@ -672,6 +672,7 @@ class Oracle:
             "bit_ME": bits["mv"],
             "mv_hat": mv_hat_out,
             "dpb": {"mv_feature": mv_feature_out, "ref_mv_y": mv["mv_y_hat"]},
+            "decoding_time": 0, "encoding_time": 0,        # pMCTF_L.py:588,611 (wall-clock, not part of any comparison)
             "files": files,
             "enc": {"H_t": luma.get("H_t_enc"), "mv_hat": mv["mv_hat"]},
             "traces": {"mv": mv["trace"], "H": luma["H_trace"], "Hc": chroma["H_trace"],

@@ -627,6 +627,64 @@ def test_batched_stage_equals_pair_by_pair(cuda):
                 np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
 
 
+def test_literal_harness_loop_1080p_vs_reference(cuda):
+    """The reference's evaluation loop itself (tests/harness_loop.py: run_test of test_pMCTF_flex.py restated statement
+    for statement — YUVReader, padding, the .to(device) calls, the isinstance checks, BOTH per-pair f-strings,
+    np.mean per stage, generate_log_json, dump_json) on the headline configuration, the product in its DEFAULT mode:
+    1920x1080, GOP 16, q_index 3, four ME stages, write_stream + skip_decoding.  Bits of every frame identical to the real
+    reference's CPU run, PSNR within 1e-4 dB, the log is plain JSON; every call was coded when it returned (no
+    encode_stage_pairs batch, results are torch.Tensors and Python floats) and from the second GOP on every pair
+    replays a captured launch plan."""
+    import json
+    import pmctf_synth
+    from harness_loop import run_sequence, write_yuv
+    from pMCTF.hip import pair_plan
+    g = np.load(_digest_path(16, 3))
+    import pmctf_synth as ps_
+    from pMCTF.models.video.pMCTF_L import pMCTF
+    net = pMCTF(num_me_stages=4).eval()                     # exactly what encode_one() of the script builds
+    net.load_state_dict(ps_.synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to("cuda")
+    net.eval()
+    net.update(force=True)
+    w, h, gop = 1920, 1080, 16
+    seen, batches, runs = [], [], []
+    orig_one, orig_stage, orig_run = net.encode_one_stage, net.encode_stage_pairs, pair_plan.PairPlan.run
+
+    def spy(**kw):
+        r = orig_one(**kw)
+        seen.append(r)
+        return r
+    net.encode_one_stage = spy
+    net.encode_stage_pairs = lambda pairs, *a, **k: (batches.append(len(pairs)), orig_stage(pairs, *a, **k))[1]
+    pair_plan.PairPlan.run = lambda self, *a, **k: (runs.append(self), orig_run(self, *a, **k))[1]
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            yuv = os.path.join(td, "Synth_1920x1080_120fps_420_8bit_YUV.yuv")
+            fr8 = pmctf_synth.synth_yuv420(w, h, gop)
+            write_yuv(yuv, fr8 + fr8)                       # two GOPs of the same frames: the second one only replays
+            bins = os.path.join(td, "bin")
+            os.makedirs(bins)
+            log, bits, psnrs, printed, text = run_sequence(net, yuv, w, h, 2 * gop, gop, 3, bins, "cuda")
+            assert len(os.listdir(bins)) == 3 * (gop - 1) + 2
+    finally:
+        pair_plan.PairPlan.run = orig_run
+    assert batches == [] and len(seen) == 2 * (gop - 1)
+    assert len(runs) == (gop - 1) - 7 + (gop - 1)           # first GOP: 7 configurations recorded, the rest replayed
+    for r in seen:                                          # finished values, call by call
+        assert all(type(r[k]) is torch.Tensor for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"))
+        assert all(type(r[k]) is float for k in ("bit_H", "bit_Hc", "bit_ME", "encoding_time"))
+        assert all(type(v) is torch.Tensor for v in r["dpb"].values())
+    ref_bits = g["gop.bits"].tolist()
+    assert bits[:gop] == ref_bits and bits[gop:] == ref_bits
+    assert np.abs(np.array(psnrs[:gop]) - g["gop.psnr_yuv"]).max() < 1e-4
+    assert psnrs[gop:] == psnrs[:gop]
+    parsed = json.loads(text)
+    assert parsed["i_frame_num"] == 2 and parsed["p_frame_num"] == 2 * (gop - 1)
+    assert abs(parsed["ave_all_frame_bpp"] - float(g["gop.bits"].sum()) / (gop * w * h)) < 1e-6
+    assert sum(l.startswith("percentage MV") for l in printed) == 2 * (gop - 1)
+
+
 def test_pair_plan_equals_stream_launches(cuda):
     """encode_one_stage replays captured launch plans (HIP graphs, luma / chroma coders on two streams) from the second
     pair of a configuration on (pMCTF.hip.pair_plan).  GOP 8 with four ME stages at 128x128, coded three times: stream
@@ -981,6 +1039,28 @@ def test_content_adaptive_driver_matches_oracle(setup, write_stream):
     else:
         assert np.allclose(a["logs"]["bits"], b["logs"]["bits"], rtol=1e-6)
     assert len(a["logs"]["bits"]) == 8 and a["logs"]["frame_types"].count(0) == 8 // a["gop_choice"]
+
+
+def test_content_adaptive_search_vs_reference_script(cuda):
+    """pmctf_ca.search_gop over the HIP product against what the REAL script produced (tests/golden/reference_ca_*.npz,
+    written by tools/make_golden.py --ca from the unmodified test_pMCTF_CA.run_test in write mode): the same options in
+    the same order (GOP 8 / 4 at full-resolution motion, then GOP 8 with motion at 1/2 and 1/4 resolution — padded to
+    128, 128 and 256), the same bits per frame in every trial, RD costs within 1e-6 relative, the same choices."""
+    import pmctf_ca
+    g = golden("reference_ca_128x128_gop8_q3.npz")
+    w, h, G, q, me, seed = (int(v) for v in g["ca.meta"])
+    net, _ = product_model(me)
+    fr8 = frames(w, h, G, seed=seed)
+    frd = [[y[:, :, :h, :w].cuda(), c[:, :, :h // 2, :w // 2].cuda()] for y, c in fr8]
+    with tempfile.TemporaryDirectory() as td:
+        r = pmctf_ca.search_gop(net, frd, h, w, q, td, write_stream=True)
+    assert [(s_, d) for s_, d, _ in r["trials"]] == [tuple(t) for t in g["ca.trials"].tolist()]
+    assert (r["gop_choice"], r["ds_choice"], r["tested_opts"]) == (int(g["ca.gop_choice"][0]), int(g["ca.ds_choice"][0]),
+                                                                  int(g["ca.tested_opts"][0]))
+    for (_, _, rd), ref in zip(r["trials"], g["ca.trial_rd"].tolist()):
+        assert abs(rd - ref) <= 1e-6 * abs(ref), (rd, ref)
+    assert np.allclose(np.array(r["logs"]["bpps"]), g["ca.frame_bpp"], rtol=0, atol=0)
+    assert np.abs(np.array(r["logs"]["psnrs"]) - g["ca.frame_psnr"]).max() < 1e-4
 
 
 def test_estimate_only_branch_of_encode_one_stage(setup):

@@ -74,6 +74,57 @@ def test_gop4_bits_and_psnr_torch_backend(sd):
             assert r["files"][name] == g[f"gop.pair{i}.file.{key}"].tobytes()
 
 
+def test_harness_loop_restatement_reproduces_the_reference_run(sd):
+    """tests/harness_loop.py (run_test of test_pMCTF_flex.py restated: .yuv reader, padding, per-pair prints, log JSON) with
+    the oracle as the codec reproduces what the REAL script's loop produced for the golden GOP-4: per-frame bits and
+    PSNR — so the GPU test that drives the product through the same helper compares like with like."""
+    import json
+    import os
+    import pmctf_synth
+    from harness_loop import run_sequence, write_yuv
+    from pmctf_oracle.model import Oracle
+    g = golden()
+    o = Oracle(sd, 1, "torch")
+    with tempfile.TemporaryDirectory() as td:
+        yuv = os.path.join(td, "seq.yuv")
+        write_yuv(yuv, pmctf_synth.synth_yuv420(W, H, 4))
+        bins = os.path.join(td, "bin")
+        os.makedirs(bins)
+        log, bits, psnrs, printed, text = run_sequence(o, yuv, W, H, 4, 4, 3, bins, "cpu")
+    assert bits == g["gop.bits"].tolist()
+    assert np.abs(np.array(psnrs) - g["gop.psnr_yuv"]).max() < 1e-4
+    parsed = json.loads(text)
+    assert abs(parsed["ave_all_frame_bpp"] - float(g["gop.bits"].sum()) / (4 * W * H)) < 1e-6
+    assert sum(l.startswith("percentage MV") for l in printed) == 3 and "STAGE 1 completed" in printed
+
+
+def test_content_adaptive_search_reproduces_the_reference_script():
+    """The build's own driver of the content-adaptive RD search (pmctf_ca.search_gop, a restatement of
+    test_pMCTF_CA.py:341-414) over the oracle against what the REAL script's run_test did on the same 8 frames
+    (tools/make_golden.py --ca, write mode): every trial in order with its per-frame bits and RD cost, the number of
+    options tested, the chosen GOP size and motion resolution, the per-frame log of the chosen option."""
+    import pmctf_ca
+    from pmctf_oracle.model import Oracle
+    g = golden("reference_ca_128x128_gop8_q3.npz")
+    w, h, G, q, me, seed = (int(v) for v in g["ca.meta"])
+    o = Oracle(synth_sd_cpu(me), me, "torch")
+    o.get_qp_num = lambda: 21
+    fr = [[y[:, :, :h, :w], c[:, :, :h // 2, :w // 2]] for y, c in frames(w, h, G, seed=seed)]
+    seen = []
+    with tempfile.TemporaryDirectory() as td, torch.no_grad():
+        r = pmctf_ca.search_gop(o, fr, h, w, q, td, write_stream=True,
+                                on_trial=lambda size, ds, logs: seen.append((size, ds, list(logs["bits"]), list(logs["psnrs"]))))
+    assert [(s_, d) for s_, d, _ in r["trials"]] == [tuple(t) for t in g["ca.trials"].tolist()]
+    assert r["tested_opts"] == int(g["ca.tested_opts"][0])
+    assert (r["gop_choice"], r["ds_choice"]) == (int(g["ca.gop_choice"][0]), int(g["ca.ds_choice"][0]))
+    for i, (_, _, bits, psnrs) in enumerate(seen):
+        assert bits == g["ca.trial_bits"][i].tolist(), i
+        assert np.abs(np.array(psnrs) - g["ca.trial_psnr_yuv"][i]).max() < 1e-4
+    assert np.allclose([t[2] for t in r["trials"]], g["ca.trial_rd"], rtol=1e-9)
+    assert np.array_equal(np.array(r["logs"]["bpps"]), g["ca.frame_bpp"])
+    assert abs(pmctf_ca.get_cur_lamda(q) - float(g["ca.lamda"][0])) < 1e-15
+
+
 @pytest.mark.parametrize("backend,rtol,ttol", [("torch", 1e-6, 1e-4), ("cdef", 2e-5, 2e-3)])
 def test_estimate_mode_forward(sd, backend, rtol, ttol):
     """forward_one_stage (bit ESTIMATES instead of range coding, pMCTF_L.py:332-379) against the real reference's

@@ -417,3 +417,71 @@ def test_deferred_values_semantics():
     assert np.asarray(t).shape == (1, 1, 2, 3)
     d = Deferred(lambda: {"H": b"abc"})
     assert d["H"] == b"abc" and "H" in d and len(d) == 1
+
+
+def _overlap_worker(rank, world, port, q, n_gops):
+    import torch.distributed as dist
+    import pmctf_dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    gops = [[[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
+            for _ in range(n_gops)]
+    stats = {}
+    ws = pmctf_dist.PairShardWorkspace()
+    with tempfile.TemporaryDirectory() as td:
+        folders = [os.path.join(td, str(j)) for j in range(n_gops)]
+        for f in folders:
+            os.makedirs(f)
+        for _ in range(2):          # twice through the same workspace: the buffers are reused, the results the same
+            encs = pmctf_dist.encode_gops_pair_sharded_overlapped(_ChainCodec(), gops, 8, 12, 3, folders, rank, world, dist,
+                                                                  stats=stats, workspace=ws)
+    q.put((rank, [(e["bits"], e["bits_mv"], [[t if t is None else t.numpy() for t in fc] for fc in e["frames_coded"]],
+                   len(e["results"])) for e in encs], stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_gops", [(4, 2), (4, 3)])
+def test_pair_sharding_overlapped_gops_gloo(world, n_gops):
+    """SURVEY 8e's GOP overlap (pmctf_dist.encode_gops_pair_sharded_overlapped): several closed GOPs in flight over the
+    same ranks, their relay chains running in opposite directions so that the late stages land on different ranks.
+    Every rank ends with every GOP's subband tree and bit counts exactly as the single-process schedule produces them;
+    the relay hop and gather counts are those of the layout."""
+    import torch.multiprocessing as mp
+    import pmctf_dist
+    import pmctf_gop
+    # the owner map: consecutive GOPs run in opposite directions, every second pair of GOPs starts half-way round
+    assert [pmctf_dist.pair_owner(p, 8, 0) for p in range(8)] == list(range(8))
+    assert [pmctf_dist.pair_owner(p, 8, 1) for p in range(8)] == list(range(7, -1, -1))
+    assert [pmctf_dist.pair_owner(p, 8, 2) for p in range(4)] == [4, 5, 6, 7]
+    assert [pmctf_dist.pair_owner(p, 8, 3) for p in range(4)] == [3, 2, 1, 0]
+    late = {pmctf_dist.pair_owner(p, 8, j) for j in range(4) for p in range(2)}      # the 2-pair stage of four GOPs
+    assert len(late) == 8
+    g = torch.Generator().manual_seed(7)
+    gops = [[[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
+            for _ in range(n_gops)]
+    refs = []
+    for fr in gops:
+        with tempfile.TemporaryDirectory() as td:
+            refs.append(pmctf_gop.encode_gop(_ChainCodec(), fr, 8, 12, 3, td))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + 7 * world + n_gops) % 2000
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, n_gops)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for j in range(n_gops):
+        assert sum(r[1][j][3] for r in res) == 15                 # each pair of each GOP coded exactly once
+    for rank, encs, stats in res:
+        for j, (bits, bits_mv, fc, _) in enumerate(encs):
+            assert bits == refs[j]["bits"] and bits_mv == refs[j]["bits_mv"], (rank, j)
+            for a, b in zip(fc, refs[j]["frames_coded"]):
+                for x, y in zip(a, b):
+                    assert (x is None and y is None) or np.array_equal(x, y.numpy()), (rank, j)
+        assert len(stats["gather_bytes_per_stage"]) == 4 * n_gops       # one all-gather per GOP and stage
+    assert sum(r[2]["relay_hops"] for r in res) == n_gops * (7 + 3 + 1)     # every chain link of every stage, once
+

@@ -75,8 +75,85 @@ def sha(a):
     return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def content_adaptive_fixture(args):
+    """--ca: the REAL content-adaptive script (test_pMCTF_CA.py: run_test with its GOP-size x motion-resolution RD
+    search, write mode) on `--gop` synthetic frames: every trial's (GOP size, motion down-sampling factor, per-frame bpp
+    and YUV-PSNR, RD cost), the choices, the per-frame log of the chosen option -> tests/golden/reference_ca_*.npz.
+    The script is imported unmodified from /root/reference; what it needs beyond the model and is absent offline is
+    stubbed in sys.modules only (none of it runs at this size): torchvision.utils.save_image (debug images),
+    pytorch_msssim.ms_ssim (guarded by pic_height > 128) and train_pWave.lamda_list (overwritten on the next line of
+    the script, test_pMCTF_CA.py:25-27)."""
+    import json
+    pMCTF, EntropyCoder = import_reference()
+    for name, attrs in (("torchvision", {}), ("torchvision.utils", {"save_image": lambda *a, **k: None}),
+                        ("pytorch_msssim", {"ms_ssim": lambda *a, **k: torch.zeros(())}),
+                        ("train_pWave", {"lamda_list": [1, 27]})):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("ref_test_pMCTF_CA", "/root/reference/test_pMCTF_CA.py")
+    ca = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ca)
+    net = pMCTF(num_me_stages=args.me_stages).eval()
+    sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
+    net.load_state_dict(sd, strict=True)
+    net.update(force=True)
+    W, H, G = args.width, args.height, args.gop
+    trials = []
+    orig = ca.code_one_gop
+
+    def spy(video_net, pic_height, pic_width, a, device, gop_size, gop_idx, me_downsample, frames_orig, *rest, **kw):
+        res = orig(video_net, pic_height, pic_width, a, device, gop_size, gop_idx, me_downsample, frames_orig, *rest, **kw)
+        trials.append((gop_size, me_downsample, list(res["bpps"]), list(res["psnrs"]), list(res["bits"])))
+        return res
+    ca.code_one_gop = spy
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        yuv = os.path.join(td, "seq.yuv")
+        with open(yuv, "wb") as f:
+            for y, u, v in pmctf_synth.synth_yuv420(W, H, G, seed=args.seed):
+                f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+        bins = os.path.join(td, "bin")
+        os.makedirs(bins)
+        a = {"frame_num": G, "gop_size": G, "last_frames": False, "frame_num_seq": G, "write_stream": True,
+             "save_decoded_frame": False, "verbose": 0, "vid_path": yuv, "src_width": W, "src_height": H,
+             "q_idx": args.q_index, "bin_folder": bins, "skip_decoding": True}
+        t0 = time.time()
+        log = ca.run_test(net, a, "cpu")
+        print(f"reference run_test (content-adaptive, write mode): {time.time() - t0:.0f} s")
+    lamda = ca.get_cur_lamda(args.q_index, net.get_qp_num())
+    # a trial of a GOP size below G is G/size consecutive code_one_gop calls (test_pMCTF_CA.py:365-381)
+    merged = []
+    i = 0
+    while i < len(trials):
+        size, ds = trials[i][0], trials[i][1]
+        n = G // size
+        bpps = sum((t[2] for t in trials[i:i + n]), [])
+        psnrs = sum((t[3] for t in trials[i:i + n]), [])
+        bits = sum((t[4] for t in trials[i:i + n]), [])
+        merged.append((size, ds, bpps, psnrs, bits, sum(bpps) + lamda * sum(ca.get_mse(psnrs))))
+        i += n
+    out = {"ca.trials": np.array([(m[0], m[1]) for m in merged], dtype=np.int32),
+           "ca.trial_rd": np.array([m[5] for m in merged], dtype=np.float64),
+           "ca.trial_bits": np.array([m[4] for m in merged], dtype=np.float64),
+           "ca.trial_psnr_yuv": np.array([m[3] for m in merged], dtype=np.float64),
+           "ca.gop_choice": np.array(log["gop_choice"], dtype=np.int32),
+           "ca.ds_choice": np.array(log["ds_choice"], dtype=np.int32),
+           "ca.tested_opts": np.array(log["tested_opts"], dtype=np.int32),
+           "ca.frame_bpp": np.array(log["frame_bpp"], dtype=np.float64),
+           "ca.frame_psnr": np.array(log["frame_psnr"], dtype=np.float64),
+           "ca.lamda": np.array([lamda], dtype=np.float64),
+           "ca.meta": np.array([W, H, G, args.q_index, args.me_stages, args.seed], dtype=np.int32)}
+    name = os.path.join(args.out, f"reference_ca_{W}x{H}_gop{G}_q{args.q_index}.npz")
+    np.savez_compressed(name, **out)
+    print("wrote", name, {k: v.tolist() for k, v in out.items() if k in ("ca.trials", "ca.trial_rd", "ca.gop_choice",
+                                                                       "ca.ds_choice", "ca.tested_opts")})
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--ca", action="store_true", help="fixture of the real content-adaptive script's RD search")
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic sequence (--ca)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--width", type=int, default=128)
     ap.add_argument("--height", type=int, default=128)
@@ -88,6 +165,8 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if args.ca:
+        return content_adaptive_fixture(args)
     pMCTF, EntropyCoder = import_reference()
 
     trace = []
