@@ -222,6 +222,7 @@ class HipEngine:
         # configuration on: luma and chroma coders on two streams, no per-launch host work
         self.use_graphs = os.environ.get("PMCTF_GRAPHS", "1") != "0"
         self.pair_plans = {}
+        self.graph_pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())    # main + luma chain, chroma chain
         self.capture_stream = torch.cuda.Stream(device=self.dev)
         # luma carries the longest symbol stream: its coder gets the high-priority queue so that the stream reaches the
         # host range coder early (measured: 5.41 vs 5.38 frames/s on the 1080p GOP-16 encode)
@@ -230,6 +231,12 @@ class HipEngine:
         self.syn_after_analysis = os.environ.get("PMCTF_SYN_AFTER_ANALYSIS", "1") != "0"
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
+
+    def release(self):
+        """drop the captured launch plans (their graphs hold device memory pools) — called when the model replaces the
+        engine"""
+        torch.cuda.synchronize(self.dev)
+        self.pair_plans.clear()
 
     # ------------------------------------------------------------------ packed layers
     def conv(self, p, stride=1, padding=0):

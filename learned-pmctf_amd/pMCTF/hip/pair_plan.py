@@ -19,8 +19,11 @@ work.  A graph replays the very kernels the stream path launches, in the same or
 results are bit-identical (tests/test_gpu_engine.py::test_pair_plan_equals_stream_launches).
 
 Static storage: a plan owns its input planes, the pinned host buffers of its symbol streams and (inside the
-graphs' private pools) every intermediate; results are copied out into fresh tensors per call, because the
-caller keeps them across the GOP (test_pMCTF_flex.py:225-226).
+graphs' memory pools) what one segment hands to the next; results are copied out into fresh tensors per call, because
+the caller keeps them across the GOP (test_pMCTF_flex.py:225-226).  All plans of an engine share TWO graph memory
+pools — one for the main / luma chain, one for the chroma chain (the two run concurrently, everything inside a chain
+and every two plans run one after the other) — so the scratch memory of the ~3 000 launches of a pair exists once per
+chain, not once per plan: ~8 GB per engine at 1080p instead of ~60.
 """
 import torch
 
@@ -28,13 +31,14 @@ import torch
 class _Capture:
     """Cuts the launches issued by ordinary Python code into a sequence of HIP graphs."""
 
-    def __init__(self):
+    def __init__(self, pool):
         self.graphs = []
         self.g = None
+        self.pool = pool
 
     def begin(self):
         self.g = torch.cuda.CUDAGraph()
-        self.g.capture_begin(capture_error_mode="thread_local")
+        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def cut(self):
         self.end()
@@ -59,8 +63,8 @@ class PairPlan:
         """ry / rc: a luma (1,1,H,W) and a chroma (2,1,H/2,W/2) plane of the size to plan for (shapes only).
         Must be called when every layer this configuration uses has been packed already (i.e. after one pair of the
         configuration went through the stream path) — packing synchronises, which a capture cannot."""
-        self.eng = eng
         dev = eng.dev
+        pool_y, pool_c = eng.graph_pools
         self.chained, self.code_lt = chained, code_lt
         _, _, H, W = ry.shape
         new = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=dev)
@@ -79,7 +83,7 @@ class PairPlan:
             self.host[k] = pin(n_y)
             self.host[k + "c"] = pin(n_c)
         self.segments = {}          # job name -> SymbolStream.segments of that bitstream
-        cap = _Capture()
+        cap = _Capture(pool_y)
         cur = torch.cuda.current_stream(dev)
         side = eng.capture_stream
         side.wait_stream(cur)
@@ -93,10 +97,11 @@ class PairPlan:
                 self.segments["mv"] = list(mv["stream"].segments)
                 cap.end()
                 self.g_me, self.g_mv = cap.graphs
-                self.mv = mv
+                self.mv = {k: mv[k] for k in ("mv_hat", "mv_feature", "mv_y_hat")}
+                del est
 
                 def analysis(ref, cur_, chroma):
-                    c = _Capture()
+                    c = _Capture(pool_c if chroma else pool_y)
                     suffix = "c" if chroma else ""
 
                     def on_stream(kind, stream):
@@ -106,13 +111,13 @@ class PairPlan:
                             c.cut()
                     c.begin()
                     try:
-                        out = eng.compress_one_stage(ref, cur_, code_lt, mv["mv_hat"], chroma, stage_idx, q_index, False,
+                        out = eng.compress_one_stage(ref, cur_, code_lt, self.mv["mv_hat"], chroma, stage_idx, q_index, False,
                                                      on_stream=on_stream, defer=True)
                         c.end()
                     except BaseException:
                         c.abort()
                         raise
-                    s = _Capture()
+                    s = _Capture(pool_c if chroma else pool_y)
                     s.begin()
                     try:
                         out["finish"]()
@@ -120,7 +125,9 @@ class PairPlan:
                     except BaseException:
                         s.abort()
                         raise
-                    return out, c.graphs, s.graphs[0]
+                    names = ("L_t_hat" if code_lt else "L_t", "H_t_hat")
+                    return {n: out[n] for n in names}, c.graphs, s.graphs[0]
+                del mv
                 self.luma, self.g_luma, self.g_luma_syn = analysis(self.in_ry, self.in_cy, False)
                 self.chroma, self.g_chroma, self.g_chroma_syn = analysis(self.in_rc, self.in_cc, True)
         except BaseException:
@@ -128,11 +135,10 @@ class PairPlan:
             raise
         cur.wait_stream(side)
 
-    def run(self, ry, cy, rc, cc, dpb, submit, on_dpb=None):
+    def run(self, eng, ry, cy, rc, cc, dpb, submit, on_dpb=None):
         """Replays the plan on the caller's frames.  dpb: the motion context (dict of logical-NCHW tensors, or a
         zero-argument callable delivering it after the motion estimation).  submit(job, hs, hi, event, segments) hands one
         bitstream's pinned symbol buffers to the range coder.  Returns the tensors of encode_one_stage's result."""
-        eng = self.eng
         A, B = eng.pair_streams
         main = torch.cuda.current_stream(eng.dev)
         for dst, src in ((self.in_ry, ry), (self.in_cy, cy), (self.in_rc, rc), (self.in_cc, cc)):

@@ -109,15 +109,20 @@ class pMCTF(nn.Module):
         self.lp_coder.update(force)
         self.hp_coder.update(force)
         if force:
-            self._engine = None
+            self._drop_engine()
 
     def load_state_dict(self, *args, **kwargs):
-        self._engine = None
+        self._drop_engine()
         return super().load_state_dict(*args, **kwargs)
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            self._engine.release()
+        self._engine = None
 
     def engine(self):
         if self._engine is not None and self._engine.precision != self.precision:
-            self._engine = None
+            self._drop_engine()
         if self._engine is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
@@ -669,7 +674,7 @@ class pMCTF(nn.Module):
             jobs[job] = eng.coder.submit_host(hs, hi, ev, segments, eng.tables, headers[job], paths[job], keep)
         if not callable(dpb):
             dpb = unwrap(dpb)
-        r = plan.run(ry, cy, rc, cc, dpb, submit, on_dpb)
+        r = plan.run(eng, ry, cy, rc, cc, dpb, submit, on_dpb)
         t_enq = time.time() - start
         done = {k: j.result() for k, j in jobs.items()}
         eng.stats["enqueue_s"] += t_enq

@@ -892,11 +892,19 @@ def _pair_shard_gpu_worker(rank, world, port, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     net, _ = product_model(4)
     fr = frames(W, H, 8, device="cuda", seed=11)
+    fr2 = frames(W, H, 8, device="cuda", seed=12)
     with tempfile.TemporaryDirectory() as td:
         enc = pmctf_dist.encode_gop_pair_sharded(net, fr, H, W, 3, td, rank, world, dist)
+        # and two closed GOPs in flight, their chains in opposite directions (SURVEY 8e's GOP overlap); the second time
+        # round the pairs replay captured launch plans, relay and all
+        os.makedirs(os.path.join(td, "b"))
+        for _ in range(2):
+            both = pmctf_dist.encode_gops_pair_sharded_overlapped(net, [fr, fr2], H, W, 3, [td, os.path.join(td, "b")],
+                                                                  rank, world, dist)
     torch.cuda.synchronize()
-    q.put((rank, enc["bits"], enc["bits_mv"],
-           [[t if t is None else t.cpu().numpy() for t in fc] for fc in enc["frames_coded"]], len(enc["results"])))
+    pack = lambda e: (e["bits"], e["bits_mv"], [[t if t is None else t.cpu().numpy() for t in fc] for fc in e["frames_coded"]],
+                      len(e["results"]))
+    q.put((rank,) + pack(enc) + (pack(both[0]), pack(both[1])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -912,6 +920,7 @@ def test_pair_sharding_two_ranks_real_codec(cuda):
     fr = frames(W, H, 8, device="cuda", seed=11)
     with tempfile.TemporaryDirectory() as td:
         ref = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+        ref2 = pmctf_gop.encode_gop(net, frames(W, H, 8, device="cuda", seed=12), H, W, 3, td)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + os.getpid() % 2000
@@ -923,11 +932,13 @@ def test_pair_sharding_two_ranks_real_codec(cuda):
         p.join(120)
         assert p.exitcode == 0
     assert sorted(r[4] for r in res) == [3, 4]             # 4+2+1 pairs: rank 0 codes 2+1+1, rank 1 codes 2+1
-    for rank, bits, bits_mv, fc, _ in res:
-        assert bits == ref["bits"] and bits_mv == ref["bits_mv"], rank
-        for a, b in zip(fc, ref["frames_coded"]):
-            for x, y in zip(a, b):
-                assert (x is None and y is None) or np.array_equal(x, y.cpu().numpy()), rank
+    for rank, bits, bits_mv, fc, _, o1, o2 in res:
+        for (b_, bm_, fc_, _), want in (((bits, bits_mv, fc, None), ref), (o1, ref), (o2, ref2)):
+            assert b_ == want["bits"] and bm_ == want["bits_mv"], rank
+            for a, b in zip(fc_, want["frames_coded"]):
+                for x, y in zip(a, b):
+                    assert (x is None and y is None) or np.array_equal(x, y.cpu().numpy()), rank
+    assert sorted(r[5][3] + r[6][3] for r in res) == [7, 7]     # overlapped: GOP A 4+3, GOP B 3+4 pairs per rank
 
 
 @pytest.mark.parametrize("K", [2, 4])

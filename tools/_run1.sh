@@ -1,4 +1,3 @@
-set -e
-mkdir -p gpurun_out/r3b
-PMCTF_LUMA_PRIORITY=-1 PMCTF_HACK_NOJOIN=1 python tools/eager_gop.py 3 > gpurun_out/r3b/eager_hack.txt 2>&1; tail -1 gpurun_out/r3b/eager_hack.txt
-PMCTF_LUMA_PRIORITY=-1 python tools/eager_gop.py 3 > gpurun_out/r3b/eager_prio2.txt 2>&1; tail -1 gpurun_out/r3b/eager_prio2.txt
+mkdir -p gpurun_out/r3c
+python tools/eager_gop.py 3 > gpurun_out/r3c/eager_pools.txt 2>&1; tail -2 gpurun_out/r3c/eager_pools.txt
+python -m pytest tests/ -x -q -m gpu > gpurun_out/r3c/pytest_gpu.txt 2>&1; echo "pytest rc=$?" ; tail -15 gpurun_out/r3c/pytest_gpu.txt | cut -c1-300

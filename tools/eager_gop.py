@@ -25,4 +25,6 @@ with torch.no_grad():
     for _ in range(n):
         enc = pmctf_gop.encode_gop(net, frames, H, W, 3, tmp, on_pair=look)
     torch.cuda.synchronize(); t = time.time() - t
+print(f"memory: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, "
+      f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; plans {len(eng.pair_plans)}")
 print(f"{G * n / t:.3f} frames/s  ({t / n * 1e3:.1f} ms per GOP)  bits {sum(enc['bits']):.0f}  stats {eng.stats}")
