@@ -15,11 +15,15 @@
 // the chain's value unchanged, so the parameters equal those of the encoder's one-shot masked convolutions bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <mutex>
 #include "pm_device_math.h"
 #include "launch.h"
 #include "../../include/pmctf_hip.h"
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 inline int launch_ok() { return pm_launch_status(); }
 inline unsigned grid_for(long n, int bs = 256, unsigned cap = 16384) {
@@ -55,7 +59,19 @@ constexpr long SZ_MB = (long)8 * TB * 16 * NF + NF;
 constexpr long W_P0 = W_MB + 5 * SZ_MB;                   // convs.0: [NF k][NF] + bias
 constexpr long W_P1 = W_P0 + (long)NF * NF + NF;          // convs.1
 constexpr long W_P2 = W_P1 + (long)NF * NF + NF;          // convs.2: [NF k][2] + bias[2]
-constexpr long W_TOTAL = W_P2 + NF * 2 + 2;
+constexpr long W_V1_TOTAL = W_P2 + NF * 2 + 2;
+// ---- second layout in the same blob, read by the streaming kernel (ll_ar_stream_kernel): the weights of the five
+// type-B layers and of the two 128 -> 128 head layers as ONE linear stream of float4 groups [group][co][4]
+// (k = 4 * group + j in the chain order of the layer), so that a thread fetches four consecutive chain weights of its
+// output channel with one 16-byte load and the whole position is a single forward sweep over 1.7 MB
+constexpr int GROUPS_B = 8 * TB * 16 / 4;                 // 160 groups per type-B layer
+constexpr int GROUPS_D = NF / 4;                          // 32 groups per dense layer ...
+constexpr int GROUPS_DP = GROUPS_D + 8;                   // ... stored as 40 (the last 8 are zero padding, never used)
+constexpr int GROUPS_TOTAL = 5 * GROUPS_B + 2 * GROUPS_DP; // 880
+constexpr long S_W = W_V1_TOTAL;                          // [GROUPS_TOTAL][NF][4]
+constexpr long S_BIAS = S_W + (long)GROUPS_TOTAL * NF * 4;   // [7][NF]: five type-B layers, two dense layers
+constexpr long S_P2 = S_BIAS + 7 * NF;                    // convs.2 as [2][NF] + bias[2]
+constexpr long W_TOTAL = S_P2 + 2 * NF + 2;
 
 __device__ __forceinline__ float leaky02(float v) { return v > 0.0f ? v : v * 0.2f; }
 
@@ -235,6 +251,291 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming form of the sequential LL decode.  What bounds a position is (a) per output channel one fmaf chain of 640
+// terms per type-B layer in the spec's order — it cannot be split — and (b) 1.7 MB of weights through one CU's L2 port.
+// The first kernel above paid for much more: five dependent global round trips per position for the causal activations,
+// weight loads issued chunk by chunk with nothing in flight behind them, the CDF row of every symbol fetched from L2.
+// Here:
+//  * 128 threads, one per output channel, each running the chains of ALL planes of the stream (chroma: two chains per
+//    weight, the weights are fetched once);
+//  * the causal activations never make a round trip on the critical path: a layer's input at (h, w-1) is the value this
+//    thread produced one position ago, the three values of row h-1 are a four-slot ring whose next element is requested a
+//    full position ahead (the scratch buffers are per-channel private: a thread only reads what it wrote itself);
+//  * the weights are one linear stream of 16-byte loads through a ring of five register blocks (four blocks = 128 chain
+//    terms, 64 KB per workgroup, in flight), which never drains: the head of the next position is requested while the
+//    symbol is decoded;
+//  * the CDF table (105 KB), the biases, the per-layer state and the 128 -> 2 head sit in LDS.
+// Same chains in the same order: bit-identical to the first kernel and to the encoder's one-shot masked convolutions.
+template <int NP>
+__global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
+    // float4 groups per ring block: 8 (32 chain terms) for one plane, 4 for two (the same time per block either way); the
+    // ring holds 40 groups either way: 72 KB of weights in flight per workgroup, what it takes to keep the L2 port busy
+    constexpr int BLK = NP == 1 ? 8 : 4;
+    constexpr int RING = NP == 1 ? 5 : 10;
+    constexpr int BLOCKS_B = GROUPS_B / BLK;              // 20 or 40: a multiple of RING
+    constexpr int BLOCKS_D = GROUPS_DP / BLK;             // 5 or 10 (the last fifth is padding that is never read)
+    constexpr int BLOCKS_TOTAL = 5 * BLOCKS_B + 2 * BLOCKS_D;
+    static_assert(BLOCKS_B % RING == 0 && BLOCKS_D % RING == 0, "a layer must start at ring slot 0");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;                          // = output channel
+    const int W = a.W, H = a.H;
+    // LDS carve-up
+    int32_t *l_cdf = (int32_t *)smem;                     // [256][cols]
+    int32_t *l_sizes = l_cdf + 256 * a.cols;
+    int32_t *l_offs = l_sizes + 256;
+    float *l_act = (float *)(l_offs + 256);               // [2][NP][TB * NF]
+    float *l_left = l_act + 2 * NP * TB * NF;             // [5][NP][NF]   layer input at (h, w-1)
+    float *l_up = l_left + 5 * NP * NF;                   // [5][NP][4][NF] layer inputs of row h-1, slot = column & 3
+    float *l_bias = l_up + 5 * NP * 4 * NF;               // [7][NF]
+    float *l_p2 = l_bias + 7 * NF;                        // [2][NF] + 2
+    float *l_prm = l_p2 + 2 * NF + 2;                     // [NP][2]
+    float *l_rows = l_prm + 2 * NP;                       // [NP][2][W + 2]: decoded values of rows h-1 / h, zero-padded
+    for (int i = tid; i < 256 * a.cols; i += NF) l_cdf[i] = a.cdf[i];
+    for (int i = tid; i < 256; i += NF) { l_sizes[i] = a.sizes[i]; l_offs[i] = a.offsets[i]; }
+    for (int i = tid; i < NP * 2 * (W + 2); i += NF) l_rows[i] = 0.0f;
+    for (int i = tid; i < 2 * NF + 2; i += NF) l_p2[i] = a.w[S_P2 + i];
+    for (int i = tid; i < 7 * NF; i += NF) l_bias[i] = a.w[S_BIAS + i];
+    const float *w = a.w;
+    const float w00 = w[W_L0 + 0 * NF + tid], w01 = w[W_L0 + 1 * NF + tid], w02 = w[W_L0 + 2 * NF + tid],
+                w10 = w[W_L0 + 3 * NF + tid], b0 = w[B_L0 + tid];
+    const f32x4 *ws = (const f32x4 *)(w + S_W) + tid;     // group g of this channel: ws[g * NF]
+    const long plane_sz = (long)H * W * NF;               // scratch: [5 layers][NP][H][W][NF]
+    float *scr = a.bufs + tid;
+    f32x4 ring[RING][BLK];
+    int nb = 0;                                           // next block of the stream to request
+    auto request = [&](int slot) {                        // slot is a compile-time constant at every use
+        const f32x4 *src = ws + (long)nb * BLK * NF;
+#pragma unroll
+        for (int g = 0; g < BLK; ++g) ring[slot][g] = src[(long)g * NF];
+        nb = nb + 1 == BLOCKS_TOTAL ? 0 : nb + 1;
+    };
+#pragma unroll
+    for (int b = 0; b < RING - 1; ++b) request(b);
+    unsigned long long x = a.x0;
+    long pos = a.pos0;
+    int err = 0;
+    __syncthreads();
+
+    for (int h = 0; h < H; ++h) {
+        float *row_prev = l_rows + ((h + 1) & 1) * (W + 2);      // + p * 2 * (W + 2)
+        float *row_cur = l_rows + (h & 1) * (W + 2);
+        // the row starts: nothing to the left; columns -1, 0, 1 of row h-1 into their slots
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float *sc = scr + ((long)l * NP + p) * plane_sz + (long)(h - 1) * W * NF;
+                float *up = l_up + ((l * NP + p) * 4) * NF + tid;
+                l_left[(l * NP + p) * NF + tid] = 0.0f;
+                up[3 * NF] = 0.0f;
+                up[0 * NF] = h > 0 ? sc[0] : 0.0f;
+                up[1 * NF] = (h > 0 && W > 1) ? sc[NF] : 0.0f;
+            }
+        for (int wq = 0; wq < W; ++wq) {
+            // next element of the window over row h-1 (column wq+2): requested now, stored when this position is done
+            float un[5][NP];
+#pragma unroll
+            for (int l = 0; l < 5; ++l)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    un[l][p] = (h > 0 && wq + 2 < W) ? scr[((long)l * NP + p) * plane_sz + ((long)(h - 1) * W + wq + 2) * NF] : 0.0f;
+            // ---- maskedConv1 (type A, 1 -> 128) on the decoded values
+            float conv1[NP], xin[NP], xres[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float *rp = row_prev + p * 2 * (W + 2) + wq, *rc = row_cur + p * 2 * (W + 2) + wq;
+                float t = b0;                             // padded rows: column wq-1 is at index wq
+                t = __builtin_fmaf(rp[0], w00, t);
+                t = __builtin_fmaf(rp[1], w01, t);
+                t = __builtin_fmaf(rp[2], w02, t);
+                t = __builtin_fmaf(rc[0], w10, t);
+                conv1[p] = t;
+                xin[p] = t;
+                xres[p] = 0.0f;
+            }
+            const long spos = ((long)h * W + wq) * NF;
+            const int s0 = (wq + 3) & 3, s1 = wq & 3, s2 = (wq + 1) & 3;      // slots of columns wq-1, wq, wq+1
+            // ---- five type-B layers
+#pragma unroll 1
+            for (int layer = 0; layer < 5; ++layer) {
+                float *A = l_act + (layer & 1) * NP * TB * NF;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    scr[((long)layer * NP + p) * plane_sz + spos] = xin[p];
+                    float *Ap = A + p * TB * NF + tid;
+                    const float *up = l_up + ((layer * NP + p) * 4) * NF + tid;
+                    float *lf = l_left + (layer * NP + p) * NF + tid;
+                    Ap[0 * NF] = up[s0 * NF];
+                    Ap[1 * NF] = up[s1 * NF];
+                    Ap[2 * NF] = up[s2 * NF];
+                    Ap[3 * NF] = lf[0];
+                    Ap[4 * NF] = xin[p];
+                    lf[0] = xin[p];
+                }
+                __syncthreads();
+                float acc[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = l_bias[layer * NF + tid];
+                // activations of a block are read from LDS one block ahead of their use (the chain must never wait for them)
+                f32x4 ab[2][NP][BLK];
+                auto read_act = [&](int blk, int buf) {
+#pragma unroll
+                    for (int g = 0; g < BLK; ++g) {
+                        const int k = (blk * BLK + g) * 4;                 // chain index of the group's first weight
+                        const int pair = k / 16, cb = pair / TB, t = pair % TB, ci = k % 16;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) ab[buf][p][g] = *(const f32x4 *)(A + p * TB * NF + t * NF + cb * 16 + ci);
+                    }
+                };
+                read_act(0, 0);
+#pragma unroll
+                for (int blk = 0; blk < BLOCKS_B; ++blk) {
+                    request((blk + RING - 1) % RING);
+                    if (blk + 1 < BLOCKS_B) read_act(blk + 1, (blk + 1) & 1);
+#pragma unroll
+                    for (int g = 0; g < BLK; ++g) {
+                        const f32x4 wv = ring[blk % RING][g];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)                   // the planes' chains interleaved: independent
+                                acc[p] = __builtin_fmaf(ab[blk & 1][p][g][j], wv[j], acc[p]);
+                    }
+                    // the chains are pure: without this the optimiser is free to sink a plane's 640 fmaf to the end of the
+                    // layer and spill every operand they need on the way
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(acc[p]));
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float o = acc[p];
+                    if (layer == 0 || layer == 2) { xres[p] = xin[p]; xin[p] = leaky02(o); }
+                    else if (layer == 1) xin[p] = o + xres[p];
+                    else if (layer == 3) xin[p] = (o + xres[p]) + conv1[p];
+                    else xin[p] = leaky02(o);
+                }
+            }
+            // ---- head: 128 -> 128 -> 128 -> 2
+#pragma unroll 1
+            for (int d = 0; d < 2; ++d) {
+                float *A = l_act + ((5 + d) & 1) * NP * TB * NF;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) A[p * TB * NF + tid] = xin[p];
+                __syncthreads();
+                float acc[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = l_bias[(5 + d) * NF + tid];
+#pragma unroll
+                for (int blk = 0; blk < BLOCKS_D; ++blk) {
+                    request((blk + RING - 1) % RING);
+                    if (blk < GROUPS_D / BLK) {           // the fifth block is padding that keeps the ring aligned
+#pragma unroll
+                        for (int g = 0; g < BLK; ++g) {
+                            const int k = (blk * BLK + g) * 4;
+                            const f32x4 wv = ring[blk % RING][g];
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {
+                                const f32x4 av = *(const f32x4 *)(A + p * TB * NF + k);
+                                acc[p] = __builtin_fmaf(av[0], wv[0], acc[p]);
+                                acc[p] = __builtin_fmaf(av[1], wv[1], acc[p]);
+                                acc[p] = __builtin_fmaf(av[2], wv[2], acc[p]);
+                                acc[p] = __builtin_fmaf(av[3], wv[3], acc[p]);
+                            }
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(acc[p]));
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xin[p] = leaky02(acc[p]);
+            }
+            {
+                float *A = l_act + (7 & 1) * NP * TB * NF;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) A[p * TB * NF + tid] = xin[p];
+                __syncthreads();
+                if (tid < 2 * NP) {                       // (plane, output) pairs: scale and mean of every plane
+                    const int p = tid >> 1, o = tid & 1;
+                    float acc = l_p2[2 * NF + o];
+                    const float *wv = l_p2 + o * NF, *av = A + p * TB * NF;
+#pragma unroll 16
+                    for (int k = 0; k < NF; ++k) acc = __builtin_fmaf(av[k], wv[k], acc);
+                    l_prm[p * 2 + o] = acc;
+                }
+                __syncthreads();
+            }
+            // ---- entropy decode (wave 0, uniform): plane after plane (pWave.py:566-575)
+            if (tid < 64) {
+#pragma unroll 1
+                for (int pl = 0; pl < NP; ++pl) {
+                    float s = l_prm[pl * 2 + 0];
+                    const float mean = l_prm[pl * 2 + 1];
+                    s = s < 1e-5f ? 1e-5f : s;
+                    float iv = (pm::logf_(s) - a.lmin) / a.lstep;
+                    iv = iv >= 0.0f ? iv : 0.0f;          // also maps NaN (corrupt stream) to row 0
+                    iv = iv > 255.0f ? 255.0f : iv;
+                    const int row = (int)iv;
+                    const int32_t *cd = l_cdf + row * a.cols;
+                    const int size = l_sizes[row];
+                    const int max_value = size - 2;
+                    const unsigned cum = (unsigned)(x & 0xFFFFull);
+                    int cnt = 0;
+                    for (int base = 0; base < size; base += 64) {
+                        const int i = base + tid;
+                        const bool le = i < size && (unsigned)cd[i] <= cum;
+                        cnt += __builtin_popcountll(__ballot(le));
+                    }
+                    const int sidx = cnt - 1;
+                    const unsigned start = (unsigned)cd[sidx], freq = (unsigned)(cd[sidx + 1] - cd[sidx]);
+                    x = (unsigned long long)freq * (x >> 16) + (x & 0xFFFFull) - start;
+                    if (x < (1ull << 31)) {
+                        if (pos < a.n_words) x = (x << 32) | a.stream[pos]; else err = 1;
+                        ++pos;
+                    }
+                    int value = sidx;
+                    if (value == max_value) {               // bypass digits (rans.cpp:303-325)
+                        auto bits4 = [&]() -> int {
+                            const int val = (int)(x & 15ull);
+                            x >>= 4;
+                            if (x < (1ull << 31)) {
+                                if (pos < a.n_words) x = (x << 32) | a.stream[pos]; else err = 1;
+                                ++pos;
+                            }
+                            return val;
+                        };
+                        int val = bits4();
+                        int n_bypass = val;
+                        while (val == 15) { val = bits4(); n_bypass += val; }
+                        int raw = 0;
+                        for (int j = 0; j < n_bypass; ++j) raw |= bits4() << (j * 4);
+                        value = raw >> 1;
+                        if (raw & 1) value = -value - 1; else value += max_value;
+                    }
+                    const float q = (float)(short)(value + l_offs[row]);
+                    if (tid == 0) {
+                        const float v = __builtin_rintf(q + mean);
+                        row_cur[pl * 2 * (W + 2) + wq + 1] = v;
+                        a.ll_out[(long)pl * H * W + (long)h * W + wq] = v;
+                    }
+                }
+            }
+            // column wq+2 of row h-1 takes the slot column wq-2 had
+#pragma unroll
+            for (int l = 0; l < 5; ++l)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) l_up[((l * NP + p) * 4 + ((wq + 2) & 3)) * NF + tid] = un[l][p];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        a.state_out[0] = x;
+        a.state_out[1] = (unsigned long long)pos;
+        a.state_out[2] = (unsigned long long)err;
+    }
+}
+
 // four-step decompress: CDF rows of step k (0 off the mask), then x_hat at the mask positions
 __device__ __forceinline__ int scale_index(float s, float lmin, float step) {
     s = s < 1e-5f ? 1e-5f : s;
@@ -359,6 +660,29 @@ extern "C" int pmctf_ll_ar_pack_weights(const float *w_a, const float *b_a, cons
         for (int co = 0; co < 2; ++co) out[W_P2 + (long)k * 2 + co] = w_p2[(long)co * NF + k];
     out[W_P2 + NF * 2 + 0] = b_p2[0];
     out[W_P2 + NF * 2 + 1] = b_p2[1];
+    // the stream layout of ll_ar_stream_kernel: [group][co][4] over the chain index k of each layer
+    long g0 = 0;
+    for (int l = 0; l < 5; ++l) {
+        for (int k = 0; k < 8 * TB * 16; ++k) {
+            const int pair = k / 16, cb = pair / TB, t = pair % TB, ci = k % 16;
+            for (int co = 0; co < NF; ++co)
+                out[S_W + ((g0 + k / 4) * NF + co) * 4 + (k & 3)] =
+                    w_b[l][((long)co * NF + cb * 16 + ci) * 9 + TBT[t][0] * 3 + TBT[t][1]];
+        }
+        for (int co = 0; co < NF; ++co) out[S_BIAS + l * NF + co] = b_b[l][co];
+        g0 += GROUPS_B;
+    }
+    for (int l = 0; l < 2; ++l) {
+        for (int k = 0; k < NF; ++k)
+            for (int co = 0; co < NF; ++co) out[S_W + ((g0 + k / 4) * NF + co) * 4 + (k & 3)] = wp[l][(long)co * NF + k];
+        for (int co = 0; co < NF; ++co) out[S_BIAS + (5 + l) * NF + co] = bp[l][co];
+        for (long i = (g0 + GROUPS_D) * NF * 4; i < (g0 + GROUPS_DP) * NF * 4; ++i) out[S_W + i] = 0.0f;
+        g0 += GROUPS_DP;
+    }
+    for (int o = 0; o < 2; ++o)
+        for (int k = 0; k < NF; ++k) out[S_P2 + o * NF + k] = w_p2[(long)o * NF + k];
+    out[S_P2 + 2 * NF + 0] = b_p2[0];
+    out[S_P2 + 2 * NF + 1] = b_p2[1];
     return PMCTF_OK;
 }
 
@@ -377,6 +701,22 @@ extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *str
     a.lmin = log_scale_min; a.lstep = log_scale_step;
     a.ll_out = ll_out; a.bufs = scratch_zeroed; a.N = N; a.H = H; a.W = W;
     a.state_out = (unsigned long long *)state_out;
+    const size_t smem = ((size_t)256 * cdf_cols + 512) * sizeof(int32_t) +
+                        ((size_t)2 * N * TB * NF + 5 * N * NF + 5 * N * 4 * NF + 7 * NF + 2 * NF + 2 + 2 * N +
+                         (size_t)N * 2 * (W + 2)) * sizeof(float) + 64;
+    static const bool v1 = getenv("PMCTF_LL_AR_V1") != nullptr;      // the first kernel, kept for A/B measurements
+    if (!v1 && N <= 2 && smem <= 150 * 1024) {       // Y and UV streams; three or four planes (RGB stills) keep the first kernel
+        static std::once_flag once[LL_MAX_PLANES];
+        auto go = [&](auto kernel, std::once_flag &flag) {
+            std::call_once(flag, [kernel] {
+                (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+            PM_LAUNCH(kernel, dim3(1), dim3(NF), smem, (hipStream_t)stream, a);
+        };
+        if (N == 1) go(ll_ar_stream_kernel<1>, once[0]);
+        else go(ll_ar_stream_kernel<2>, once[1]);
+        return launch_ok();
+    }
     PM_LAUNCH(ll_ar_decode_kernel, dim3(1), dim3(128 * N), 0, (hipStream_t)stream, a);
     return launch_ok();
 }

@@ -221,6 +221,7 @@ class HipEngine:
         # encode_one_stage replays captured launch plans (HIP graphs, pMCTF.hip.pair_plan) from the second pair of a
         # configuration on: luma and chroma coders on two streams, no per-launch host work
         self.use_graphs = os.environ.get("PMCTF_GRAPHS", "1") != "0"
+        self._dec_pool = None
         self.pair_plans = {}
         self.graph_pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())    # main + luma chain, chroma chain
         self.capture_stream = torch.cuda.Stream(device=self.dev)
@@ -1020,7 +1021,29 @@ class HipEngine:
         while len(self.side_streams) < len(jobs):
             self.side_streams.append(torch.cuda.Stream(device=self.dev))
         begun = [self.pwave_decompress_begin(*j, stream=self.side_streams[i]) for i, j in enumerate(jobs)]
-        return [self.pwave_decompress_end(b) for b in begun]
+        if len(begun) == 1:
+            return [self.pwave_decompress_end(begun[0])]
+        # The files are independent: each is finished by its own host thread on its own stream (the four-step decode
+        # alternates GPU network evaluations with host range decoding, so one file alone leaves both sides idle half the
+        # time; ctypes and the device waits release the GIL).  Chroma's subbands are decoded while luma's four times
+        # longer sequential LL part is still running on its CU.
+        main = torch.cuda.current_stream(self.dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+
+        def finish(i):
+            torch.cuda.set_device(self.dev)
+            st = self.side_streams[i]
+            st.wait_event(ready)
+            with torch.no_grad(), torch.cuda.stream(st):
+                return self.pwave_decompress_end(begun[i])
+        if self._dec_pool is None:
+            self._dec_pool = ThreadPoolExecutor(max_workers=4)
+        out = list(self._dec_pool.map(finish, range(len(begun))))
+        for i, t in enumerate(out):
+            main.wait_stream(self.side_streams[i])
+            t.record_stream(main)
+        return out
 
     def pwave_decompress_end(self, job):
         coder, dec, N = job["coder"], job["dec"], job["N"]

@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r3c
-python tools/eager_gop.py 3 > gpurun_out/r3c/eager_pools.txt 2>&1; tail -2 gpurun_out/r3c/eager_pools.txt
-python -m pytest tests/ -x -q -m gpu > gpurun_out/r3c/pytest_gpu.txt 2>&1; echo "pytest rc=$?" ; tail -15 gpurun_out/r3c/pytest_gpu.txt | cut -c1-300
+mkdir -p gpurun_out/r3d
+python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "decoder or still_image or cross_decode or full_size or corrupt" > gpurun_out/r3d/pytest_dec.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3d/pytest_dec.txt
+PROFILE=0 python tools/decode_profile.py > gpurun_out/r3d/decode_profile_H.txt 2>&1; grep -v amdgpu gpurun_out/r3d/decode_profile_H.txt
+PROFILE=0 python tools/decode_profile.py L > gpurun_out/r3d/decode_profile_L.txt 2>&1; grep -v amdgpu gpurun_out/r3d/decode_profile_L.txt
