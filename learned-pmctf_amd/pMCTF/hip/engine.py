@@ -215,6 +215,7 @@ class HipEngine:
         self.motion_overlap = os.environ.get("PMCTF_MOTION_OVERLAP", "1") != "0"
         self.motion_stream = torch.cuda.Stream(device=self.dev)
         self.lt_event, self.lt_tensor = None, None       # event behind the last batched luma lifting + that L_t tensor
+        self.lt_stream = None                            # ... and the stream it was recorded on
         self.pu_fused = os.environ.get("PMCTF_PU_FUSED", "1") != "0"     # one launch per PredictUpdate + lifting step
         self.pu_fused_max_px = int(os.environ.get("PMCTF_PU_FUSED_MAX_PX", "400000"))
         self.post_process_max_px = 8 * 1152 * 1920      # pixels per post-processing launch group (4.5 GB per 64-ch map)
@@ -868,9 +869,9 @@ class HipEngine:
         mv_all = torch.cat(flows, dim=0)
         L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_all, stage_idx)
         if not ischroma:      # the next stage's motion estimation may start from here (its inputs are slices of L_t)
-            self.lt_event = torch.cuda.Event()
-            self.lt_event.record()
-            self.lt_tensor = L_t
+            ev = torch.cuda.Event()
+            ev.record()
+            self.lt_event, self.lt_tensor, self.lt_stream = ev, L_t, torch.cuda.current_stream(self.dev).cuda_stream
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
         H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, False, defer=True, per_push=True)
         out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "L_t_hat": None}

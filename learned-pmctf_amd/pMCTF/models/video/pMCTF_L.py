@@ -95,6 +95,7 @@ class pMCTF(nn.Module):
         self.lazy_stages = os.environ.get("PMCTF_LAZY", "0") == "1"
         self.lazy_max_pairs = int(os.environ.get("PMCTF_LAZY_MAX_PAIRS", "32"))
         self._tls = threading.local()
+        self._atexit = False
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -156,8 +157,14 @@ class pMCTF(nn.Module):
         tensor only enqueues the GPU work.)"""
         self._run_pending()
         files, self._tls.files = self._pending_files(), []
+        first = None
         for f in files:
-            f.result()
+            try:
+                f.result()
+            except BaseException as e:  # noqa: BLE001 - wait for every writer, then report the first failure
+                first = first or e
+        if first is not None:
+            raise first
 
     def _run_pending(self, q=None):
         """Enqueue the GPU work of every pair collected so far (one encode_stage_pairs call); does not wait for the
@@ -183,6 +190,13 @@ class pMCTF(nn.Module):
     def _defer(self, ref_frame, cur_frame, code_lt, dpb, output_path, pic_width, pic_height, psize, stage_idx, q_index,
                me_downsample=1):
         q = self._queue()
+        if not self._atexit:
+            # deferred pairs still queued when the interpreter exits are coded then (their files must exist)
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref().flush())
+            self._atexit = True
         # inputs produced by pairs that are still pending (a later temporal stage): they are needed now
         if any(is_pending(t) for t in (*ref_frame, *cur_frame)):
             self._run_pending()
@@ -318,8 +332,10 @@ class pMCTF(nn.Module):
         overlap = eng.motion_overlap
         if overlap:
             side = eng.motion_stream
-            if eng.lt_event is not None and all(t is eng.lt_tensor or t._base is eng.lt_tensor for t in lumas):
-                side.wait_event(eng.lt_event)        # inputs are slices of the previous stage's batched L_t
+            lt_event, lt_tensor = eng.lt_event, eng.lt_tensor      # one snapshot: another host thread may replace them
+            if lt_event is not None and eng.lt_stream == main.cuda_stream and \
+                    all(t is lt_tensor or t._base is lt_tensor for t in lumas):
+                side.wait_event(lt_event)            # inputs are slices of the previous stage's batched L_t
             else:
                 side.wait_stream(main)
             for t in lumas:
@@ -394,6 +410,8 @@ class pMCTF(nn.Module):
             chroma["finish"]()
         results = []
         pending = self._pending_files()
+        for f in [f for f in pending if f.done()]:
+            f.result()                      # a writer thread's error (e.g. an unwritable folder) surfaces here, not never
         pending[:] = [f for f in pending if not f.done()]
         for i in range(P):
             # Bit counts are the sizes of the files the range-coder threads are still writing.  wait_files=True (a direct
