@@ -283,9 +283,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_wave_kernel(SplitArgs a)
     const int nkb = a.ncb * KB_PER_CHUNK;
     // fragments of (K block kbi, cout tile mt, plane s): 1 KB each, this lane's 16 bytes
     const unsigned char *wq = (const unsigned char *)a.wp + (size_t)mb * nkb * MT * NS * 1024 + lane * 16;
-    bf16x8 a_cur[NS], a_nxt[NS];
+    // DEEP: the fragments of a whole K block (MT x NS) are requested one K block ahead (28 MFMAs = ~450 cycles of cover
+    // instead of one cout tile = 4 MFMAs); costs MT*NS*4 more registers, so only where they are free
+    constexpr bool DEEP = (MT * NS <= 8);
+    bf16x8 a_cur[DEEP ? MT : 1][NS], a_nxt[DEEP ? MT : 1][NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a_cur[s] = *(const bf16x8 *)(wq + s * 1024);
+    for (int m = 0; m < (DEEP ? MT : 1); ++m)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a_cur[m][s] = *(const bf16x8 *)(wq + (m * NS + s) * 1024);
     fetch(0);
     stash();
     long wstep = 0;                                   // (kbi * MT + mt): fragment group being multiplied
@@ -304,22 +309,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_wave_kernel(SplitArgs a)
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) b[nt][s] = *(const bf16x8 *)(bsrc + s * 2 * REGION + nt * PW * 16);
+            if (DEEP) {
+                const long kn = (long)(cb * KB_PER_CHUNK + kb + 1) * MT;       // first fragment group of the next K block
+                const long k0 = kn < wsteps ? kn : 0;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) a_nxt[DEEP ? m : 0][s] = *(const bf16x8 *)(wq + ((k0 + m) * NS + s) * 1024);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 ++wstep;
-                {   // next fragment group, always loaded (the last one re-reads the first: no branch)
+                if (!DEEP) {   // next fragment group, always loaded (the last one re-reads the first: no branch)
                     const long wn = wstep < wsteps ? wstep : 0;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) a_nxt[s] = *(const bf16x8 *)(wq + (wn * NS + s) * 1024);
+                    for (int s = 0; s < NS; ++s) a_nxt[0][s] = *(const bf16x8 *)(wq + (wn * NS + s) * 1024);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int t = 0; t < n_terms(NS); ++t)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[term_a(NS, t)], b[nt][term_b(NS, t)],
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[DEEP ? mt : 0][term_a(NS, t)], b[nt][term_b(NS, t)],
                                                                               acc[mt][nt], 0, 0, 0);
+                if (!DEEP) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) a_cur[s] = a_nxt[s];
+                    for (int s = 0; s < NS; ++s) a_cur[0][s] = a_nxt[0][s];
+                }
+            }
+            if (DEEP) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) a_cur[DEEP ? m : 0][s] = a_nxt[DEEP ? m : 0][s];
             }
         }
         if (more) stash();       // in-order LDS: after this wave's last read of the chunk

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-signature census of the convolutions of one 1080p GOP-16 encode (stage-batched schedule): launches, time,
-TFLOP/s (HIP events)."""
+"""Per-signature census of the convolutions of one 1080p GOP-16 encode: launches, time, TFLOP/s (HIP events on one
+stream).  CENSUS_SCHEDULE=pairs: the harness loop pair by pair through stream launches (the shapes the default path
+replays from its launch plans); default: the stage-batched schedule."""
 import collections, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "learned-pmctf_amd"))
@@ -18,11 +19,14 @@ sigs = []
 def match(conv, x, stride):
     sigs.append((tuple(x.shape), conv.Cout, conv.KH, stride))
     return True
+pairs = os.environ.get("CENSUS_SCHEDULE") == "pairs"
+net.engine().use_graphs = False
+run = (lambda: pmctf_gop.encode_gop(net, frames, H, W, 3, tmp)) if pairs else (lambda: pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp))
 with torch.no_grad():
-    pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
+    run(); torch.cuda.synchronize()
     probe = {"match": match, "events": []}
     ops.CONV_PROBE = probe
-    pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp); torch.cuda.synchronize()
+    run(); torch.cuda.synchronize()
     ops.CONV_PROBE = None
 agg = collections.OrderedDict()
 for s, (e0, e1, fl) in zip(sigs, probe["events"]):
