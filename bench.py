@@ -520,12 +520,19 @@ def main():
                 k_p = max(1, min(args.steps, 2))
                 t_p, _ = timed(step_main, k_p, 1)
                 e_p = last["enc"]
+
+                def batched():
+                    last["enc_b"] = pmctf_gop.encode_gop_batched(net, frames, H, W, args.q_index, tmp)
+                t_pb, _ = timed(batched, k_p, 1)
                 ps_p = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, [list(f) for f in e_p["frames_coded"]]), frames, H, W)
                 blk = {"value": args.gop * k_p / t_p, "unit": "frames/s", "ms_per_step": t_p / k_p * 1e3, "steps": k_p,
                        "dtype": {"bf16x3": "bf16 x3 split operands, f32 accumulate", "bf16x2": "bf16 x2 split, f32 accumulate",
                                  "bf16": "bf16, f32 accumulate"}.get(prec, prec),
                        "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px (conv_split.hip); all else exact f32",
                        "schedule": sched_text[args.schedule],
+                       "stage_batched": {"value": args.gop * k_p / t_pb, "ms_per_step": t_pb / k_p * 1e3,
+                                         "schedule": sched_text["stages"],
+                                         "bits_identical_to_this_profile_pair_by_pair": last.pop("enc_b")["bits"] == e_p["bits"]},
                        "bpp": sum(e_p["bits"]) / (args.gop * W * H), "psnr_yuv": sum(p["yuv"] for p in ps_p) / len(ps_p),
                        "rel_bits_vs_exact_profile": (sum(e_p["bits"]) - sum(enc["bits"])) / sum(enc["bits"]),
                        "max_abs_dpsnr_vs_exact_profile_db": max(abs(p["yuv"] - q["yuv"]) for p, q in zip(ps_p, ps))}

@@ -941,6 +941,59 @@ def test_pair_sharding_two_ranks_real_codec(cuda):
     assert sorted(r[5][3] + r[6][3] for r in res) == [7, 7]     # overlapped: GOP A 4+3, GOP B 3+4 pairs per rank
 
 
+def _pair_shard_1080p_worker(rank, world, port, q):
+    import hashlib
+    import torch.distributed as dist
+    import pmctf_dist
+    import pmctf_gop
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    net, _ = product_model(4)
+    w, h, gop = 1920, 1080, 16
+    fr = frames(w, h, gop, device="cuda")
+    stats = {}
+    with tempfile.TemporaryDirectory() as td:
+        enc = pmctf_dist.encode_gop_pair_sharded(net, fr, h, w, 3, td, rank, world, dist, stats=stats)
+        files = sorted(os.listdir(td))
+    rec = pmctf_gop.decode_gop(net, [list(f) for f in enc["frames_coded"]])     # every rank holds the whole subband tree
+    ps = [p["yuv"] for p in pmctf_gop.gop_psnr(rec, fr, h, w)]
+    tree = hashlib.sha1()
+    for fc in enc["frames_coded"]:
+        for t in fc:
+            if t is not None:
+                tree.update(t.contiguous().cpu().numpy().tobytes())
+    torch.cuda.synchronize()
+    q.put((rank, enc["bits"], enc["bits_mv"], ps, tree.hexdigest(), len(enc["results"]), files, stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_sharding_two_ranks_1080p_gop16_vs_reference(cuda):
+    """BASELINE configs[4] at its OWN workload (1920x1080, GOP 16, q_index 3, four ME stages) on what one box allows: two
+    fresh processes share the GPU, pair k of every temporal stage on rank k mod 2, motion context relayed rank to rank,
+    one all-gather of the subband tree per stage (gloo here, RCCL on the 8-GPU node).  Both ranks must end with the bits of
+    every frame the REAL reference's CPU run produced, its PSNR within 1e-4 dB after the temporal synthesis of the gathered
+    tree, and the same tree; every bitstream file is written by exactly one rank."""
+    import torch.multiprocessing as mp
+    g = np.load(_digest_path(16, 3))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pair_shard_1080p_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(r[5] for r in res) == [7, 8]                 # 8+4+2+1 pairs: rank 0 codes 4+2+1+1, rank 1 codes 4+2+1
+    assert res[0][4] == res[1][4]                              # the same subband tree on both ranks
+    for rank, bits, bits_mv, ps, _, _, files, stats in res:
+        assert bits == g["gop.bits"].tolist() and bits_mv == g["gop.bits_mv"].tolist(), rank
+        assert np.abs(np.array(ps) - g["gop.psnr_yuv"]).max() < 1e-4
+        assert len(stats["gather_bytes_per_stage"]) == 4 and stats["relay_bytes_per_hop"] == 4 * 64 * (288 * 480 + 72 * 120)
+    assert sum(r[7]["relay_hops"] for r in res) == 7 + 3 + 1
+
+
 @pytest.mark.parametrize("K", [2, 4])
 def test_cross_gop_batched_equals_gop_by_gop(cuda, K):
     """pmctf_gop.encode_gops_batched (stage s of K closed GOPs in one encode_stage_pairs call, motion context restarted

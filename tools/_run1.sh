@@ -1,4 +1,13 @@
-mkdir -p gpurun_out/r3d
-python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "decoder or still_image or cross_decode or full_size or corrupt" > gpurun_out/r3d/pytest_dec.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3d/pytest_dec.txt
-PROFILE=0 python tools/decode_profile.py > gpurun_out/r3d/decode_profile_H.txt 2>&1; grep -v amdgpu gpurun_out/r3d/decode_profile_H.txt
-PROFILE=0 python tools/decode_profile.py L > gpurun_out/r3d/decode_profile_L.txt 2>&1; grep -v amdgpu gpurun_out/r3d/decode_profile_L.txt
+mkdir -p gpurun_out/r3g
+python -m pytest tests/ -x -q -m gpu > gpurun_out/r3g/pytest_gpu.txt 2>&1; echo "pytest rc=$?" ; tail -4 gpurun_out/r3g/pytest_gpu.txt | cut -c1-200
+python bench.py --steps 3 > gpurun_out/r3g/bench.json 2> gpurun_out/r3g/bench.err; echo "bench rc=$?"; tail -2 gpurun_out/r3g/bench.err
+python - <<'PY'
+import json
+j=json.loads([l for l in open('gpurun_out/r3g/bench.json') if l.startswith('{')][-1])
+print('value', j['value'], 'roofline', j['roofline']['achieved'], j['roofline']['frac'], 'wall', j['bench_wall_s'])
+for k in ('stream_launches_single_stream','deferred_store_only','stage_batched','cross_gop_batched'):
+    print(k, j.get(k,{}).get('value'))
+print('decode', j.get('decode_pair'))
+print({k:(v['value'], v['vs_reference_cpu']['frames_with_identical_bits'], v['vs_reference_cpu']['max_abs_dpsnr_db']) for k,v in j.get('aux_profiles',{}).items()})
+print(j.get('aux_errors'), j.get('aux_skipped_over_budget'))
+PY
