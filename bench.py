@@ -196,6 +196,10 @@ def main():
     net = net.to(dev)
     net.update(force=True)
 
+    if args.inflight > 1:
+        # several host threads drive the engine: launch plans are for one (a stream capture cannot coexist with another
+        # thread's device synchronisations), so this mode uses stream launches throughout
+        net.engine().use_graphs = False
     W, H = args.width, args.height
 
     def gop_frames(seed):

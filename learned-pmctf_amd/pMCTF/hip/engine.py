@@ -11,6 +11,7 @@ Weights are packed once per prefix (first use) from the owning module's state_di
 Arithmetic follows the PM-F32 spec, which makes results bit-identical to the oracle's
 C restatement (oracle/, test infrastructure) and byte-identical bitstreams.
 """
+import contextlib
 import math
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -166,6 +167,47 @@ class RangeCoderPool:
         return futures
 
 
+class CaptureGate:
+    """Stream capture tolerates no device synchronisation, pinned allocation or allocator growth anywhere in the process
+    while it lasts, so a host thread that records a launch plan needs the engine to itself: model entry points hold the
+    gate shared, a recording holds it exclusively (it gives up its own shared hold first, so two recorders cannot wait
+    for each other).  With one host thread — the reference harness — the gate is never contended."""
+
+    def __init__(self):
+        self.cond = threading.Condition()
+        self.readers = 0
+        self.writer = False
+
+    @contextlib.contextmanager
+    def shared(self):
+        with self.cond:
+            while self.writer:
+                self.cond.wait()
+            self.readers += 1
+        try:
+            yield
+        finally:
+            with self.cond:
+                self.readers -= 1
+                self.cond.notify_all()
+
+    @contextlib.contextmanager
+    def exclusive_from_shared(self):
+        with self.cond:
+            self.readers -= 1
+            self.cond.notify_all()
+            while self.writer or self.readers > 0:
+                self.cond.wait()
+            self.writer = True
+        try:
+            yield
+        finally:
+            with self.cond:
+                self.writer = False
+                self.readers += 1
+                self.cond.notify_all()
+
+
 class HipEngine:
     PRECISIONS = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
 
@@ -224,21 +266,35 @@ class HipEngine:
         self.use_graphs = os.environ.get("PMCTF_GRAPHS", "1") != "0"
         self._dec_pool = None
         self.pair_plans = {}
-        self.graph_pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())    # main + luma chain, chroma chain
-        self.capture_stream = torch.cuda.Stream(device=self.dev)
-        # luma carries the longest symbol stream: its coder gets the high-priority queue so that the stream reaches the
-        # host range coder early (measured: 5.41 vs 5.38 frames/s on the 1080p GOP-16 encode)
-        prio = int(os.environ.get("PMCTF_LUMA_PRIORITY", "-1"))
-        self.pair_streams = (torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Stream(device=self.dev))
+        self._plan_ctx = {}             # per host thread: graph memory pools and streams of its launch plans
+        self.gate = CaptureGate()
+        self.host_threads = set()
         self.syn_after_analysis = os.environ.get("PMCTF_SYN_AFTER_ANALYSIS", "1") != "0"
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
+
+    def plan_context(self):
+        """Graph memory pools (main + luma chain, chroma chain) and the two coder streams of the CALLING host thread's
+        launch plans.  Plans of one thread run one after the other and may share scratch memory; plans of different
+        threads (bench.py --inflight) replay concurrently and must not.  luma carries the longest symbol stream: its
+        coder gets the high-priority queue so that the stream reaches the host range coder early (measured: 5.41 vs
+        5.38 frames/s on the 1080p GOP-16 encode)."""
+        tid = threading.get_ident()
+        ctx = self._plan_ctx.get(tid)
+        if ctx is None:
+            prio = int(os.environ.get("PMCTF_LUMA_PRIORITY", "-1"))
+            ctx = self._plan_ctx[tid] = {
+                "pools": (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()),
+                "streams": (torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Stream(device=self.dev)),
+                "capture": torch.cuda.Stream(device=self.dev)}
+        return ctx
 
     def release(self):
         """drop the captured launch plans (their graphs hold device memory pools) — called when the model replaces the
         engine"""
         torch.cuda.synchronize(self.dev)
         self.pair_plans.clear()
+        self._plan_ctx.clear()
 
     # ------------------------------------------------------------------ packed layers
     def conv(self, p, stride=1, padding=0):

@@ -38,7 +38,7 @@ class _Capture:
 
     def begin(self):
         self.g = torch.cuda.CUDAGraph()
-        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self.g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
 
     def cut(self):
         self.end()
@@ -64,7 +64,7 @@ class PairPlan:
         Must be called when every layer this configuration uses has been packed already (i.e. after one pair of the
         configuration went through the stream path) — packing synchronises, which a capture cannot."""
         dev = eng.dev
-        pool_y, pool_c = eng.graph_pools
+        pool_y, pool_c = eng.plan_context()["pools"]
         self.chained, self.code_lt = chained, code_lt
         _, _, H, W = ry.shape
         new = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=dev)
@@ -85,7 +85,7 @@ class PairPlan:
         self.segments = {}          # job name -> SymbolStream.segments of that bitstream
         cap = _Capture(pool_y)
         cur = torch.cuda.current_stream(dev)
-        side = eng.capture_stream
+        side = eng.plan_context()["capture"]
         side.wait_stream(cur)
         try:
             with torch.cuda.stream(side):
@@ -139,7 +139,7 @@ class PairPlan:
         """Replays the plan on the caller's frames.  dpb: the motion context (dict of logical-NCHW tensors, or a
         zero-argument callable delivering it after the motion estimation).  submit(job, hs, hi, event, segments) hands one
         bitstream's pinned symbol buffers to the range coder.  Returns the tensors of encode_one_stage's result."""
-        A, B = eng.pair_streams
+        A, B = eng.plan_context()["streams"]
         main = torch.cuda.current_stream(eng.dev)
         for dst, src in ((self.in_ry, ry), (self.in_cy, cy), (self.in_rc, rc), (self.in_cc, cc)):
             dst.copy_(src)

@@ -33,6 +33,35 @@ from pMCTF.models.pWave import pWave
 from pMCTF.utils.stream_helper import decode_p, image_header, mv_header
 
 
+def _gated(fn):
+    """hold the engine's capture gate (shared) for the duration of a model entry point; re-entrant per thread"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        tls = self._tls
+        if getattr(tls, "gated", False):
+            return fn(self, *a, **k)
+        try:
+            eng = self.engine()
+        except RuntimeError:                # no GPU / update() not called: the entry point raises its own error
+            return fn(self, *a, **k)
+        with eng.gate.shared():
+            # Launch plans are for ONE host thread driving the engine (the reference harness).  Once a second thread shows
+            # up (bench.py --inflight), recording stops for good: a capture cannot coexist with another thread's device
+            # synchronisations, pinned allocations or event queries, and that thread waited at the gate until the capture
+            # in progress, if any, was over.
+            eng.host_threads.add(threading.get_ident())
+            if len(eng.host_threads) > 1:
+                eng.use_graphs = False
+            tls.gated = True
+            try:
+                return fn(self, *a, **k)
+            finally:
+                tls.gated = False
+    return wrapper
+
+
 class MVCoderQuad(nn.Module):
     """four-part MV latent coder (pMCTF/layers/video/four_part_prior.py) — parameter-free; the arithmetic is the
     pmctf_mv_fourpart_step_f32 kernel."""
@@ -242,6 +271,7 @@ class pMCTF(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
+    @_gated
     def inverse_MCTF(self, L_t, H_t, mv_hat, downscale=False, stage_idx=0):
         """pMCTF_L.py:314-330"""
         L_t, H_t, mv_hat = unwrap((L_t, H_t, mv_hat))
@@ -249,6 +279,7 @@ class pMCTF(nn.Module):
         return self.engine().inverse_MCTF(c(L_t), c(H_t), c(mv_hat), downscale=downscale, stage_idx=stage_idx)
 
     @torch.no_grad()
+    @_gated
     def forward_MCTF(self, ref_frame, cur_frame, mv_hat, stage_idx=0):
         """pMCTF_L.py:297-312"""
         ref_frame, cur_frame, mv_hat = unwrap((ref_frame, cur_frame, mv_hat))
@@ -261,6 +292,7 @@ class pMCTF(nn.Module):
             raise ValueError("me_downsample must be 1, 2, 4 or 8")
 
     @torch.no_grad()
+    @_gated
     def decompress_mv(self, string, dtype, height, width, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """pMCTF_L.py:497-523 — returns mv_hat (1,2,H,W) and the MV decoder contexts (logical NCHW views)"""
         self._check_ds(me_downsample)
@@ -271,6 +303,7 @@ class pMCTF(nn.Module):
                 "mv_y_hat": d["mv_y_hat"].permute(0, 3, 1, 2)}
 
     @torch.no_grad()
+    @_gated
     def decompress_one_stage(self, file_name, code_lt, ischroma, psize=128, q_index=0, stage_idx=0):
         """pMCTF_L.py:422-439"""
         return self._decompress_files([(file_name, ischroma)], code_lt, psize, q_index, stage_idx)[0]
@@ -301,6 +334,7 @@ class pMCTF(nn.Module):
         return out
 
     @torch.no_grad()
+    @_gated
     def encode_stage_pairs(self, pairs, code_lt, dpb, output_paths, pic_width, pic_height, psize=128, stage_idx=0,
                            q_index=0, chain_reset=(), me_downsample=1, wait_files=True):
         """All pairs of one temporal stage in one call: pairs = [(ref_frame, cur_frame)], output_paths = ["k.bin"].
@@ -449,6 +483,7 @@ class pMCTF(nn.Module):
         return [(1, 64, h // 4, w // 4), (1, 64, h // 16, w // 16)]
 
     @torch.no_grad()
+    @_gated
     def advance_dpb(self, ref_frame, cur_frame, dpb, stage_idx=0, q_index=0, me_downsample=1):
         """The motion part of encode_one_stage only (pMCTF_L.py:448-495): returns the `dpb` the NEXT pair of the stage
         needs.  Used by pair-level sharding (pmctf_dist.encode_gop_pair_sharded): the context chain of the motion codec
@@ -463,6 +498,7 @@ class pMCTF(nn.Module):
         return {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
 
     @torch.no_grad()
+    @_gated
     def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):
         """Estimate-mode stage (pMCTF_L.py:332-379): the same networks as encode_one_stage with Laplace / factorized
         bit estimates instead of range coding.  ref_frame / cur_frame are (N,1,H,W) planes (Y, or UV with the luma
@@ -506,6 +542,7 @@ class pMCTF(nn.Module):
         return self.forward_one_stage(ref_frame, cur_frame, q_index, code_lt, dpb, stage_idx=stage_idx)
 
     @torch.no_grad()
+    @_gated
     def encode_one_stage(self, ref_frame, cur_frame, code_lt, dpb, output_path=None, pic_width=None, pic_height=None,
                          psize=128, skip_decoding=False, stage_idx=0, q_index=0, me_downsample=1, on_dpb=None):
         """Write-stream branch of pMCTF_L.py:525-637 for one frame pair.
@@ -665,11 +702,19 @@ class pMCTF(nn.Module):
         if keep:
             result["files"] = {k: v[1] for k, v in done.items()}
             result["traces"] = {k: v[2] for k, v in done.items()}
-        if plan_key is not None:
+        if plan_key is not None and eng.use_graphs and len(eng.host_threads) <= 1:
             # every layer of this configuration is packed now: record its launches, the next such pair replays them
             from pMCTF.hip.pair_plan import PairPlan
-            eng.pair_plans[plan_key] = PairPlan(eng, ref_y, ref_chroma, plan_key[3], bool(code_lt), stage_idx, q_index,
-                                                me_downsample)
+            try:
+                with eng.gate.exclusive_from_shared():
+                    torch.cuda.synchronize(dev)
+                    eng.pair_plans[plan_key] = PairPlan(eng, ref_y, ref_chroma, plan_key[3], bool(code_lt), stage_idx,
+                                                        q_index, me_downsample)
+            except Exception as e:  # noqa: BLE001 - recording is an optimisation: keep coding through stream launches
+                import warnings
+                warnings.warn(f"pMCTF: recording the launch plan failed ({type(e).__name__}: {e}); this engine goes on "
+                              f"with stream launches (same results)")
+                eng.use_graphs = False
         return result
 
     def _encode_pair_planned(self, plan, ry, cy, rc, cc, code_lt, dpb, output_path, pic_width, pic_height, on_dpb):

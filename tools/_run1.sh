@@ -1,13 +1,8 @@
-mkdir -p gpurun_out/r3g
-python -m pytest tests/ -x -q -m gpu > gpurun_out/r3g/pytest_gpu.txt 2>&1; echo "pytest rc=$?" ; tail -4 gpurun_out/r3g/pytest_gpu.txt | cut -c1-200
-python bench.py --steps 3 > gpurun_out/r3g/bench.json 2> gpurun_out/r3g/bench.err; echo "bench rc=$?"; tail -2 gpurun_out/r3g/bench.err
+mkdir -p gpurun_out/r3h
+python bench.py --steps 2 --inflight 2 --no_aux --no_cpu_baseline > gpurun_out/r3h/bench_inflight2.json 2> gpurun_out/r3h/bench_inflight2.err; echo "rc=$?"; tail -3 gpurun_out/r3h/bench_inflight2.err
 python - <<'PY'
 import json
-j=json.loads([l for l in open('gpurun_out/r3g/bench.json') if l.startswith('{')][-1])
-print('value', j['value'], 'roofline', j['roofline']['achieved'], j['roofline']['frac'], 'wall', j['bench_wall_s'])
-for k in ('stream_launches_single_stream','deferred_store_only','stage_batched','cross_gop_batched'):
-    print(k, j.get(k,{}).get('value'))
-print('decode', j.get('decode_pair'))
-print({k:(v['value'], v['vs_reference_cpu']['frames_with_identical_bits'], v['vs_reference_cpu']['max_abs_dpsnr_db']) for k,v in j.get('aux_profiles',{}).items()})
-print(j.get('aux_errors'), j.get('aux_skipped_over_budget'))
+j=json.loads([l for l in open('gpurun_out/r3h/bench_inflight2.json') if l.startswith('{')][-1])
+print('inflight2 value', j['value'], j['parity_vs_reference_cpu'])
 PY
+python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "pair_plan or literal_harness or deferred or decoder" > gpurun_out/r3h/pytest.txt 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/r3h/pytest.txt | cut -c1-200
