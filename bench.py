@@ -314,7 +314,7 @@ def main():
                             "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
                                         "rank, one all-gather of the subband tree per stage",
                             "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
-            if args.overlap_gops > 1 and hasattr(pmctf_dist, "encode_gops_pair_sharded_overlapped"):
+            if args.overlap_gops > 1 and world >= 3:     # with two ranks the GOPs would be coded one after the other
                 G2 = args.overlap_gops
                 gops = [frames0] + [gop_frames(1234 + 1000 * k) for k in range(1, G2)]
                 folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_o{k}_") for k in range(1, G2)]

@@ -43,13 +43,14 @@ def gather_gop_metrics(local, n_gops, gop, dist=None, device="cpu"):
 # Results are identical to pmctf_gop.encode_gop on one device.  On the GPU node the backend is "nccl" (= RCCL over xGMI:
 # device tensors, all_gather_into_tensor); under "gloo" (CPU tests, one-GPU rehearsal) records are staged through host
 # memory.
-def pair_owner(pair_idx, world, gop_idx=0):
-    """rank that codes pair `pair_idx` of a stage.  Closed GOPs coded together (encode_gops_pair_sharded_overlapped) run
-    their chains in opposite directions with a shifted start — GOP 0: pair k on rank k, GOP 1: pair k on rank N-1-k,
-    GOP 2: pair k on rank k + N/2, ... — so that the late stages of the GOPs (4, 2, 1 pairs) land on different ranks."""
-    shift = (gop_idx // 2) * max(1, world // 2)
-    k = (pair_idx + shift) % world
-    return k if gop_idx % 2 == 0 else world - 1 - k
+def pair_owner(pair_idx, world, gop_idx=0, n_gops=1):
+    """rank that codes pair `pair_idx` of a stage.  Closed GOPs coded together (encode_gops_pair_sharded_overlapped) all
+    run their chains in the SAME direction (rank r hands the motion context to rank r+1) from shifted starts — GOP j of G:
+    pair k on rank k + j*N/G — so that the late stages of the GOPs (4, 2, 1 pairs) land on different ranks.  One direction
+    matters under RCCL: the point-to-point operations between two ranks share one communicator and execute in issue
+    order, so contexts travelling r -> r+1 for one GOP and r+1 -> r for another could wait for each other for ever."""
+    shift = (gop_idx * world) // max(1, n_gops)
+    return (pair_idx + shift) % world
 
 
 def _is_nccl(dist):
@@ -139,8 +140,10 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
     idle in its late stages (4, 2, 1 pairs) code the other's.  With 8 ranks and two GOP-16s the critical path is
     2 + 1 + 1 + 1 pair-times for 32 frames instead of 2 x 4.  Per GOP-stage: one relay chain and ONE all-gather, exactly as
     in encode_gop_pair_sharded; a rank works through its pairs of a stage in the order of their position in their chain
-    (lowest first, which keeps the two chains moving from both ends and cannot deadlock: every wait is for a pair with a
-    lower position).  Returns one encode_gop-style dict per GOP, identical to coding them one after the other."""
+    (lowest first: every wait is for a pair with a lower position, so the chains cannot deadlock, and the sends r -> r+1 of
+    the GOPs are issued in the order rank r+1 issues its receives).  With fewer than three ranks the two neighbours of a
+    rank are the same rank and one communicator would carry both directions: under RCCL the GOPs are then coded one
+    after the other.  Returns one encode_gop-style dict per GOP, identical to coding them one after the other."""
     import math
     import os
     G = len(gops)
@@ -151,6 +154,9 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
         raise ValueError("pair sharding over world > 1 ranks needs an initialised torch.distributed")
     device = gops[0][0][0].device
     multi = dist is not None and world > 1
+    if multi and G > 1 and world < 3 and _is_nccl(dist):
+        return [encode_gops_pair_sharded_overlapped(codec, [g], pic_height, pic_width, q_index, [f], rank, world, dist, psize,
+                                                    stats, workspace)[0] for g, f in zip(gops, bin_folders)]
     y0, c0 = gops[0][0]
     shapes = [tuple(y0.shape), tuple(c0.shape), tuple(y0.shape), tuple(c0.shape), (1, 2) + tuple(y0.shape[2:])]
     offs, sc_off, rec_bytes = _record_layout(shapes)
@@ -170,7 +176,7 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
         mine = [ws.get(("mine", j, stage_idx), (slots, rec_bytes), device) for j in range(G)]
         last_dpb = [{"mv_feature": None, "ref_mv_y": None} for _ in range(G)]
         # this rank's pairs of the stage, lowest chain position first
-        tasks = sorted((p, j) for j in range(G) for p in range(num_frames) if pair_owner(p, world, j) == rank)
+        tasks = sorted((p, j) for j in range(G) for p in range(num_frames) if pair_owner(p, world, j, G) == rank)
         for p, j in tasks:
             o = outs[j]
             i_ref = p * 2 * step
@@ -185,11 +191,11 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
             elif world == 1:
                 dpb_in = last_dpb[j]
             else:
-                dpb_in = (lambda src=pair_owner(p - 1, world, j): relay.recv(src))
+                dpb_in = (lambda src=pair_owner(p - 1, world, j, G): relay.recv(src))
 
             def on_dpb(d, p=p, j=j):
                 if multi and p + 1 < num_frames:
-                    relay.send(d, pair_owner(p + 1, world, j))
+                    relay.send(d, pair_owner(p + 1, world, j, G))
 
             r = codec.encode_one_stage(ref_frame=[y_ref, c_ref], cur_frame=[y_cur, c_cur],
                                        output_path=os.path.join(bin_folders[j], f"{i_cur}.bin"), pic_height=pic_height,
@@ -222,7 +228,7 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
             for p in range(num_frames):
                 i_ref = p * 2 * step
                 i_cur = i_ref + step
-                own = pair_owner(p, world, j)
+                own = pair_owner(p, world, j, G)
                 rec = everything[own, p // world]
                 L_t, L_tc, H_t, H_tc, mv_hat = [rec[o_:o_ + 4 * n].view(torch.float32).view(shp)
                                                 for (o_, n), shp in zip(offs, shapes)]

@@ -938,7 +938,7 @@ def test_pair_sharding_two_ranks_real_codec(cuda):
             for a, b in zip(fc_, want["frames_coded"]):
                 for x, y in zip(a, b):
                     assert (x is None and y is None) or np.array_equal(x, y.cpu().numpy()), rank
-    assert sorted(r[5][3] + r[6][3] for r in res) == [7, 7]     # overlapped: GOP A 4+3, GOP B 3+4 pairs per rank
+    assert sorted(r[5][3] + r[6][3] for r in res) == [7, 7]     # overlapped: GOP A 4+3, GOP B (started one rank on) 3+4
 
 
 def _pair_shard_1080p_worker(rank, world, port, q):

@@ -450,13 +450,15 @@ def test_pair_sharding_overlapped_gops_gloo(world, n_gops):
     import torch.multiprocessing as mp
     import pmctf_dist
     import pmctf_gop
-    # the owner map: consecutive GOPs run in opposite directions, every second pair of GOPs starts half-way round
-    assert [pmctf_dist.pair_owner(p, 8, 0) for p in range(8)] == list(range(8))
-    assert [pmctf_dist.pair_owner(p, 8, 1) for p in range(8)] == list(range(7, -1, -1))
-    assert [pmctf_dist.pair_owner(p, 8, 2) for p in range(4)] == [4, 5, 6, 7]
-    assert [pmctf_dist.pair_owner(p, 8, 3) for p in range(4)] == [3, 2, 1, 0]
-    late = {pmctf_dist.pair_owner(p, 8, j) for j in range(4) for p in range(2)}      # the 2-pair stage of four GOPs
+    # the owner map: every chain runs rank r -> r+1, GOP j of G starts j*N/G ranks further on
+    assert [pmctf_dist.pair_owner(p, 8, 0, 2) for p in range(8)] == list(range(8))
+    assert [pmctf_dist.pair_owner(p, 8, 1, 2) for p in range(8)] == [4, 5, 6, 7, 0, 1, 2, 3]
+    assert [pmctf_dist.pair_owner(p, 8, 1, 4) for p in range(4)] == [2, 3, 4, 5]
+    assert [pmctf_dist.pair_owner(p, 8, 3, 4) for p in range(4)] == [6, 7, 0, 1]
+    late = {pmctf_dist.pair_owner(p, 8, j, 4) for j in range(4) for p in range(2)}   # the 2-pair stage of four GOPs
     assert len(late) == 8
+    for j in range(4):                                  # one direction: the next pair of a chain is on the next rank
+        assert all(pmctf_dist.pair_owner(p + 1, 8, j, 4) == (pmctf_dist.pair_owner(p, 8, j, 4) + 1) % 8 for p in range(8))
     g = torch.Generator().manual_seed(7)
     gops = [[[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
             for _ in range(n_gops)]
