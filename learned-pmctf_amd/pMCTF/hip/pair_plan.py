@@ -28,6 +28,9 @@ chain, not once per plan: ~8 GB per engine at 1080p instead of ~60.
 import torch
 
 
+_BROKEN = []
+
+
 class _Capture:
     """Cuts the launches issued by ordinary Python code into a sequence of HIP graphs."""
 
@@ -55,6 +58,9 @@ class _Capture:
                 self.g.capture_end()
             except Exception:  # noqa: BLE001 - the original error is the one to report
                 pass
+            # a graph object whose capture was invalidated throws from its destructor (which ends the process): it is
+            # kept alive for good instead
+            _BROKEN.append(self.g)
             self.g = None
 
 

@@ -580,6 +580,7 @@ class pMCTF(nn.Module):
         dev = ref_y.device
         c = lambda t: t.to(dev).contiguous()
         plan_key = None
+        relayed = callable(dpb) or on_dpb is not None
         if eng.use_graphs and skip_decoding and dev.type == "cuda":
             chained = callable(dpb) or dpb["mv_feature"] is not None
             plan_key = (threading.get_ident(), tuple(ref_y.shape), tuple(ref_chroma.shape), chained, bool(code_lt), stage_idx,
@@ -702,6 +703,11 @@ class pMCTF(nn.Module):
         if keep:
             result["files"] = {k: v[1] for k, v in done.items()}
             result["traces"] = {k: v[2] for k, v in done.items()}
+        if relayed and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_backend() == "nccl":
+            # the context of this pair travels over RCCL, whose watchdog thread queries events at any moment: no stream
+            # capture beside it (a plan recorded earlier, e.g. by bench.py's GOP-level phase, is still replayed)
+            plan_key = None
         if plan_key is not None and eng.use_graphs and len(eng.host_threads) <= 1:
             # every layer of this configuration is packed now: record its launches, the next such pair replays them
             from pMCTF.hip.pair_plan import PairPlan
