@@ -1,14 +1,11 @@
-mkdir -p gpurun_out/r3k
-python -m pytest tests/ -x -q -m gpu > gpurun_out/r3k/pytest_gpu.txt 2>&1; echo "pytest rc=$?" ; tail -4 gpurun_out/r3k/pytest_gpu.txt | cut -c1-200
-python bench.py > gpurun_out/r3k/bench.json 2> gpurun_out/r3k/bench.err; echo "bench rc=$?"; tail -2 gpurun_out/r3k/bench.err
+mkdir -p gpurun_out/r3m
+python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "decoder_round" > gpurun_out/r3m/pytest.txt 2>&1; echo "pytest rc=$?"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d /tmp/trd -o dec --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/time_decode.py > $GRAFT_REPO_ROOT/gpurun_out/r3m/trace_dec.txt 2>&1
+cd $GRAFT_REPO_ROOT
+grep decoding gpurun_out/r3m/trace_dec.txt
 python - <<'PY'
-import json
-j=json.loads([l for l in open('gpurun_out/r3k/bench.json') if l.startswith('{')][-1])
-print('value', j['value'], 'roofline', j['roofline']['achieved'], j['roofline']['frac'], 'wall', j['bench_wall_s'])
-for k in ('stream_launches_single_stream','deferred_store_only','stage_batched','cross_gop_batched'):
-    print(k, j.get(k,{}).get('value'))
-print('decode', {k:v for k,v in j.get('decode_pair',{}).items() if k in ('h_pair','h_and_l_pair')})
-print({k:(v['value'], v['stage_batched']['value'], v['vs_reference_cpu']['frames_with_identical_bits']) for k,v in j.get('aux_profiles',{}).items()})
-print(j.get('aux_errors'), j.get('aux_skipped_over_budget'), j['cpu_baseline']['value'])
+import csv
+rows=[r for r in csv.DictReader(open('/tmp/trd/dec_kernel_trace.csv')) if 'll_ar' in r['Kernel_Name']]
+for r in rows: print(r['Kernel_Name'][:60], (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6, 'ms')
 PY
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
