@@ -422,6 +422,15 @@ def main():
             leg("roofline", roofline_pass)
         if "roofline" not in out:
             out["roofline"] = roofline_of([], {}, traffic, "failed")
+        if headline and args.schedule == "pairs":
+            # every convolution of the timed region against the same roof: 323.6 TFLOP per 1080p GOP-16 as this build
+            # computes it (profiles/round3_conv_census_pairs.txt: every conv launch of one GOP, 2 FLOP per MAC; the
+            # reference's own count is 353 TFLOP, the difference is the exact quarter-resolution evaluation of DESIGN §5)
+            e2e = 323.6e12 * frames_total / args.gop / elapsed / 1e12
+            out["roofline"]["end_to_end_timed_region"] = {
+                "achieved": e2e, "unit": "TFLOP/s", "frac": e2e / (PEAK_F32_MFMA * world),
+                "note": "all convolution FLOPs of the timed steps / their wall time (motion estimation, codecs, lifting, "
+                        "entropy networks, post-processing; elementwise work and the host range coder included in the time)"}
 
         # ---- not optional: the CPU baseline -------------------------------------------------------------------------------
         if world == 1 and not args.no_cpu_baseline:
