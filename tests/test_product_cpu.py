@@ -487,3 +487,50 @@ def test_pair_sharding_overlapped_gops_gloo(world, n_gops):
         assert len(stats["gather_bytes_per_stage"]) == 4 * n_gops       # one all-gather per GOP and stage
     assert sum(r[2]["relay_hops"] for r in res) == n_gops * (7 + 3 + 1)     # every chain link of every stage, once
 
+
+def test_capture_gate_excludes_other_threads_while_recording():
+    """The gate around model entry points (pMCTF.hip.engine.CaptureGate): any number of threads hold it shared; a thread
+    that records a launch plan gives up its own shared hold, waits for the others to leave, holds it exclusively — during
+    which nobody can enter — and is back to shared afterwards; two recorders cannot wait for each other."""
+    import threading
+    import time
+    from pMCTF.hip.engine import CaptureGate
+    gate = CaptureGate()
+    log, lock = [], threading.Lock()
+
+    def say(x):
+        with lock:
+            log.append(x)
+
+    def worker(name, record):
+        for _ in range(3):
+            with gate.shared():
+                say((name, "in"))
+                time.sleep(0.005)
+                if record:
+                    with gate.exclusive_from_shared():
+                        say((name, "rec+"))
+                        assert gate.writer and gate.readers == 0
+                        time.sleep(0.01)
+                        say((name, "rec-"))
+                    assert gate.readers >= 1 and not gate.writer
+                say((name, "out"))
+    ts = [threading.Thread(target=worker, args=(n, r)) for n, r in (("a", True), ("b", True), ("c", False))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+        assert not t.is_alive()                 # no deadlock with two recorders
+    assert gate.readers == 0 and not gate.writer
+    inside = None                               # nothing of another thread between a recorder's rec+ and rec-
+    for name, what in log:
+        if what == "rec+":
+            assert inside is None
+            inside = name
+        elif what == "rec-":
+            assert inside == name
+            inside = None
+        else:
+            assert inside is None or inside == name, log
+    assert sum(1 for _, w in log if w == "rec+") == 6
+
