@@ -57,6 +57,11 @@ int64_t pmctf_conv2d_packed_bias_size(int Cout);
  * wave-private kernel with one cout tile per workgroup on cout-split 3x3 planes that fill the waves' 4x16 tiles to >= 90 %.
  * Environment only: PMCTF_FEWCOUT_LDS=0 / PMCTF_DWCONV_COLUMN=0 select the older one/two-cout and depthwise kernels. */
 int pmctf_conv2d_set_option(const char *name, long value);
+/* current value of a knob (-1: unknown name).  The launch plans of the drop-in path record their convolutions with
+ * "SPLIT" = 0: luma's and chroma's coders run side by side there, the other stream fills the tail of a launch, and
+ * cutting a launch into whole rounds + remainder only adds launches (5.41 -> 5.49 frames/s on the 1080p GOP-16 encode);
+ * on a single stream the cut pays (the default). */
+long pmctf_conv2d_get_option(const char *name);
 /* Measurement aid (no reference counterpart): which kernel(s) the LAST pmctf_conv2d_nhwc[_geom]_f32 call of the calling
  * thread launched — kernel expression, tile parameters and grid, several joined by " + " when the launch was cut
  * (whole rounds of workgroups + remainder).  bench.py names the kernel behind its roofline figure from this. */

@@ -1691,6 +1691,13 @@ extern "C" int pmctf_conv2d_set_option(const char *name, long value) {
     return PMCTF_EINVAL;
 }
 
+extern "C" long pmctf_conv2d_get_option(const char *name) {
+    if (!name) return -1;
+    for (Knob &k : g_knobs)
+        if (!strcmp(k.name, name)) return knob(name);
+    return -1;
+}
+
 extern "C" int64_t pmctf_conv2d_packed_bias_size(int Cout) {
     int MT, MB;
     choose_mt(Cout, MT, MB);

@@ -267,6 +267,7 @@ class HipEngine:
         self._dec_pool = None
         self.pair_plans = {}
         self._plan_ctx = {}             # per host thread: graph memory pools and streams of its launch plans
+        self.plan_timing = None         # a list: launch plans append (start, motion, luma, chroma, luma syn, chroma syn) events
         self.gate = CaptureGate()
         self.host_threads = set()
         self.syn_after_analysis = os.environ.get("PMCTF_SYN_AFTER_ANALYSIS", "1") != "0"

@@ -22,6 +22,7 @@ _SIGS = {
     "pmctf_conv2d_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
     "pmctf_conv2d_set_option": (ci, [C.c_char_p, C.c_long]),
     "pmctf_conv2d_last_launch": (ci, [C.c_char_p, ci]),
+    "pmctf_conv2d_get_option": (C.c_long, [C.c_char_p]),
     "pmctf_conv2d_nhwc_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
     "pmctf_conv2d_nhwc_geom_f32": (ci, [vp] * 6 + [ci] * 13 + [cf, vp]),
     "pmctf_conv2d_smallcin_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),

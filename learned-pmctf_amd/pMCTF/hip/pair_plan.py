@@ -25,6 +25,8 @@ pools — one for the main / luma chain, one for the chroma chain (the two run c
 and every two plans run one after the other) — so the scratch memory of the ~3 000 launches of a pair exists once per
 chain, not once per plan: ~8 GB per engine at 1080p instead of ~60.
 """
+import os
+
 import torch
 
 
@@ -89,6 +91,19 @@ class PairPlan:
             self.host[k] = pin(n_y)
             self.host[k + "c"] = pin(n_c)
         self.segments = {}          # job name -> SymbolStream.segments of that bitstream
+        # The coders of a plan run side by side: the other stream fills the tail of a launch, so the convolutions are
+        # recorded WITHOUT the whole-rounds + remainder cut that pays on a single stream (process-wide knob of the conv
+        # dispatcher; nothing else launches while a plan is recorded, see HipEngine.gate)
+        from . import lib as _lib
+        L = _lib.hip()
+        split_knob = L.pmctf_conv2d_get_option(b"SPLIT")
+        L.pmctf_conv2d_set_option(b"SPLIT", int(os.environ.get("PMCTF_PLAN_SPLIT", "0")))
+        try:
+            self._record(eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample)
+        finally:
+            L.pmctf_conv2d_set_option(b"SPLIT", split_knob)
+
+    def _record(self, eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample):
         cap = _Capture(pool_y)
         cur = torch.cuda.current_stream(dev)
         side = eng.plan_context()["capture"]
@@ -156,7 +171,11 @@ class PairPlan:
             for k in ("mv_feature", "ref_mv_y"):
                 self.in_dpb[k].copy_(dpb[k])
         self.g_mv.replay()
-        mark = lambda: torch.cuda.Event()
+        timing = eng.plan_timing is not None
+        mark = lambda: torch.cuda.Event(enable_timing=timing)
+        if timing:
+            e_start = mark()
+            e_start.record(main)
         e_mv = mark()
         e_mv.record(main)
         fresh = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=eng.dev)
@@ -190,6 +209,13 @@ class PairPlan:
                 for o, n in zip(outs, names):
                     o.copy_(out[n])
             res["L_t" + suffix], res["H_t" + suffix] = outs
+        if timing:
+            e_syn = []
+            for st in (A, B):
+                e = mark()
+                e.record(st)
+                e_syn.append(e)
+            eng.plan_timing.append((e_start, e_mv, done[0], done[1], e_syn[0], e_syn[1]))
         main.wait_stream(A)
         main.wait_stream(B)
         return res

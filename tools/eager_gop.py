@@ -12,6 +12,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 net = pMCTF(num_me_stages=4).eval()
 net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), strict=True)
 net = net.cuda(); net.update(force=True)
+from pMCTF.hip import lib as _lib
+for kv in os.environ.get("CONV_OPTIONS", "").split(","):       # NAME=VALUE launch-shape knobs (pmctf_conv2d_set_option)
+    if kv:
+        k, v = kv.split("=")
+        assert _lib.hip().pmctf_conv2d_set_option(k.encode(), int(v)) == 0
 net.lazy_stages = len(sys.argv) > 2 and sys.argv[2] == "lazy"
 W, H, G = 1920, 1080, 16
 frames = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420(W, H, G)]
@@ -21,10 +26,16 @@ with torch.no_grad():
     pmctf_gop.encode_gop(net, frames, H, W, 3, tmp, on_pair=look); torch.cuda.synchronize()
     eng = net.engine()
     for k in eng.stats: eng.stats[k] = 0
+    if os.environ.get("PLAN_TIMING"):
+        eng.plan_timing = []
     t = time.time()
     for _ in range(n):
         enc = pmctf_gop.encode_gop(net, frames, H, W, 3, tmp, on_pair=look)
     torch.cuda.synchronize(); t = time.time() - t
+if eng.plan_timing:
+    print("per pair, ms after the call's first launch: motion codec done | luma analysis done | chroma analysis done | luma synthesis done | chroma synthesis done")
+    for ev in eng.plan_timing[:15]:
+        print("   " + "  ".join(f"{ev[0].elapsed_time(e):7.1f}" for e in ev[1:]))
 print(f"memory: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, "
       f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; plans {len(eng.pair_plans)}")
 print(f"{G * n / t:.3f} frames/s  ({t / n * 1e3:.1f} ms per GOP)  bits {sum(enc['bits']):.0f}  stats {eng.stats}")
