@@ -286,7 +286,8 @@ class HipEngine:
             prio = int(os.environ.get("PMCTF_LUMA_PRIORITY", "-1"))
             ctx = self._plan_ctx[tid] = {
                 "pools": (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()),
-                "streams": (torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Stream(device=self.dev)),
+                "streams": (torch.cuda.Stream(device=self.dev, priority=prio),
+                            torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("PMCTF_CHROMA_PRIORITY", "0")))),
                 "capture": torch.cuda.Stream(device=self.dev)}
         return ctx
 
