@@ -10,6 +10,7 @@ from pMCTF.hip import ops, engine
 net = pMCTF(num_me_stages=4).eval()
 net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), strict=True)
 net = net.cuda(); net.update(force=True)
+net.engine().use_graphs = False          # count the launches themselves, not plan replays
 W, H, G = 1920, 1080, 16
 frames = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420(W, H, G)]
 tmp = tempfile.mkdtemp()
