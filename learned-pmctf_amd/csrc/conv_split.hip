@@ -226,8 +226,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_split_kernel(SplitArgs a) 
 // registers, one cout tile ahead of their use: with two waves per SIMD a K block lasts twice its MFMA time, which halves
 // the fragment bandwidth a CU needs (about 31 B/clk for three planes, within L1's 64) — and without barriers the waves
 // drift apart, so one wave's patch staging (fetch, split, LDS writes) hides behind its SIMD partner's MFMAs.
-template <int MT, int NS>
-__global__ __launch_bounds__(256, 2) void conv3x3_split_wave_kernel(SplitArgs a) {
+template <int MT, int NS, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     constexpr int PATCH = NS * 2 * REGION;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_wave_kernel(SplitArgs a)
     const unsigned char *wq = (const unsigned char *)a.wp + (size_t)mb * nkb * MT * NS * 1024 + lane * 16;
     // DEEP: the fragments of a whole K block (MT x NS) are requested one K block ahead (28 MFMAs = ~450 cycles of cover
     // instead of one cout tile = 4 MFMAs); costs MT*NS*4 more registers, so only where they are free
-    constexpr bool DEEP = (MT * NS <= 8);
+    constexpr bool DEEP = (MT * NS <= 8) || OCC == 1;      // one workgroup per CU: 512 registers per wave, always deep
     bf16x8 a_cur[DEEP ? MT : 1][NS], a_nxt[DEEP ? MT : 1][NS];
 #pragma unroll
     for (int m = 0; m < (DEEP ? MT : 1); ++m)
@@ -400,12 +400,12 @@ int launch_split(const SplitArgs &a, int MB, hipStream_t st) {
     return pm_launch_status();
 }
 
-template <int MT, int NS>
+template <int MT, int NS, int OCC = 2>
 int launch_split_wave(SplitArgs a, int MB, hipStream_t st) {
     constexpr size_t smem = (size_t)4 * NS * 2 * REGION;
     a.tiles_y = (a.H + 7) / 8;                      // 8x32-pixel workgroups of four wave tiles
     dim3 grid(a.tiles_x * a.tiles_y, a.N, MB);
-    PM_LAUNCH((conv3x3_split_wave_kernel<MT, NS>), grid, dim3(256), smem, st, a);
+    PM_LAUNCH((conv3x3_split_wave_kernel<MT, NS, OCC>), grid, dim3(256), smem, st, a);
     return pm_launch_status();
 }
 
@@ -416,7 +416,18 @@ int dispatch_ns(const SplitArgs &a, int MB, int nsplit, hipStream_t st) {
     //   fragments shared through LDS:         x3 160 / 169   x2 260 / 286   x1 455 / 382
     // (the two-plane product is L1-bound without sharing and barrier-bound with it).  PMCTF_SPLIT_VARIANT forces one.
     static const int forced = [] { const char *v = getenv("PMCTF_SPLIT_VARIANT"); return v ? atoi(v) : -1; }();
-    const int variant = forced >= 0 ? forced : ((nsplit == 2 && MT == 7) ? 0 : 1);
+    // round 3: for two planes and 112 couts the barrier-free kernel compiled for ONE workgroup per CU budget (accumulators
+    // in AGPRs, the fragments of a whole K block requested a block ahead) beats both: 257 -> 341-378
+    // (two planes x 112 couts) and 191 -> 204 (three planes x 64 couts); elsewhere it ties or loses (x3 / 112: 188 vs 205)
+    const int variant = forced >= 0 ? forced : (((nsplit == 2 && MT == 7) || (nsplit == 3 && MT == 4)) ? 2 : 1);
+    if (variant == 2) {         // one workgroup per CU, every fragment a K block ahead (PMCTF_SPLIT_VARIANT=2)
+        switch (nsplit) {
+        case 3: return launch_split_wave<MT, 3, 1>(a, MB, st);
+        case 2: return launch_split_wave<MT, 2, 1>(a, MB, st);
+        case 1: return launch_split_wave<MT, 1, 1>(a, MB, st);
+        default: return PMCTF_EINVAL;
+        }
+    }
     if (variant == 1) {
         switch (nsplit) {
         case 3: return launch_split_wave<MT, 3>(a, MB, st);
