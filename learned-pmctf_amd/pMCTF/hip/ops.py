@@ -18,7 +18,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 # Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
 # dominant kernel).  CONV_PROBE = {"match": fn(conv, x, stride) -> bool, "events": [(start, end, flops)]}
 CONV_PROBE = None
-SPLIT_MIN_PX = 30000       # planes below this keep the exact f32 kernels under the reduced-precision profile (too few tiles)
+# planes below this keep the exact f32 kernels under the reduced-precision profile (too few tiles)
+SPLIT_MIN_PX = int(os.environ.get("PMCTF_SPLIT_MIN_PX", "30000"))
 
 
 def _stream():
