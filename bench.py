@@ -155,6 +155,8 @@ def main():
                     help="what `value` times with N > 1.  gops: every rank codes its own GOP (weak scaling, no data-path "
                          "collective; the pair-sharded layout is then timed as the `pair_sharded` block).  pairs: ONE GOP, "
                          "the pairs of each temporal stage spread over the ranks (strong scaling).")
+    ap.add_argument("--pair_shard_timeout_s", type=float, default=240.0,
+                    help="watchdog of the `pair_sharded` block: print the line without it when it has not finished by then")
     ap.add_argument("--pair_shard_steps", type=int, default=2, help="steps of the `pair_sharded` block (N > 1; 0 to skip)")
     ap.add_argument("--overlap_gops", type=int, default=2,
                     help="closed GOPs in flight in the `pair_sharded` block's overlapped variant (SURVEY 8e)")
@@ -288,54 +290,6 @@ def main():
                            ("; results DEFERRED (PMCTF_LAZY=1)" if net.lazy_stages else ""),
                   "stages": "all pairs of a temporal stage as one batch (encode_stage_pairs)"}
 
-    # ---- the north-star multi-GPU layout over the same ranks (N > 1): pairs of ONE GOP spread over the GPUs
-    pair_sharded = None
-    if world > 1 and args.shard == "gops" and args.pair_shard_steps > 0:
-        import pmctf_dist
-        frames0 = frames if rank == 0 else gop_frames(1234)       # every rank reads the same GOP (rank 0's)
-        stats = {}
-
-        def sharded():
-            last["ps"] = pmctf_dist.encode_gop_pair_sharded(net, frames0, H, W, args.q_index, tmp, rank, world, dist,
-                                                            stats=stats)
-        blocks = {}
-        try:
-            with torch.no_grad():
-                t_ps, _ = timed(sharded, args.pair_shard_steps, 1)
-            tt = torch.tensor([t_ps], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_ps = float(tt.item())
-            pair_sharded = {"value": args.gop * args.pair_shard_steps / t_ps, "unit": "frames/s", "scaling": "strong",
-                            "ms_per_step": t_ps / args.pair_shard_steps * 1e3, "steps": args.pair_shard_steps,
-                            "speedup_vs_one_gpu_coding_this_gop": (elapsed / args.steps) / (t_ps / args.pair_shard_steps),
-                            "gather_bytes_per_stage": stats.get("gather_bytes_per_stage"),
-                            "relay_hops": stats.get("relay_hops"), "relay_bytes_per_hop": stats.get("relay_bytes_per_hop"),
-                            "collective": "all_gather_into_tensor (RCCL)" if dist.get_backend() == "nccl" else "all_gather (gloo)",
-                            "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
-                                        "rank, one all-gather of the subband tree per stage",
-                            "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
-            if args.overlap_gops > 1 and world >= 3:     # with two ranks the GOPs would be coded one after the other
-                G2 = args.overlap_gops
-                gops = [frames0] + [gop_frames(1234 + 1000 * k) for k in range(1, G2)]
-                folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_o{k}_") for k in range(1, G2)]
-
-                def overlapped():
-                    last["po"] = pmctf_dist.encode_gops_pair_sharded_overlapped(net, gops, H, W, args.q_index, folders,
-                                                                                rank, world, dist)
-                with torch.no_grad():
-                    t_po, _ = timed(overlapped, max(1, args.pair_shard_steps // 2), 1)
-                tt = torch.tensor([t_po], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                n_po = max(1, args.pair_shard_steps // 2)
-                pair_sharded["overlapped_gops"] = {
-                    "gops_in_flight": G2, "value": G2 * args.gop * n_po / float(tt.item()), "unit": "frames/s",
-                    "ms_per_step": float(tt.item()) / n_po * 1e3, "steps": n_po,
-                    "schedule": f"{G2} closed GOPs interleaved: ranks idle in the late stages of one GOP code the early stages "
-                                f"of the next (SURVEY 8e)",
-                    "bits_identical_to_rank0_gop": (last["po"][0]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
-        except Exception as e:  # noqa: BLE001 - an auxiliary block must never cost the headline line
-            pair_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
-
     if rank == 0:
         enc = last["enc"]
         rec = pmctf_gop.decode_gop(net, [list(f) for f in enc["frames_coded"]])
@@ -359,8 +313,6 @@ def main():
             "bpp": sum(enc["bits"]) / (args.gop * W * H),
             "psnr_yuv": sum(p["yuv"] for p in ps) / len(ps),
         }
-        if pair_sharded is not None:
-            out["pair_sharded"] = pair_sharded
         # "+ bpp/PSNR parity vs CPU ref" of BASELINE's metric: rank 0 codes exactly the sequence the real reference was
         # run on (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 16 --me_stages 4 [--q_index q]);
         # compare with the digests of that run (data, tests/golden/).
@@ -432,6 +384,74 @@ def main():
                 "note": "all convolution FLOPs of the timed steps / their wall time (motion estimation, codecs, lifting, "
                         "entropy networks, post-processing; elementwise work and the host range coder included in the time)"}
 
+
+    # ---- the north-star multi-GPU layout over the same ranks (N > 1): pairs of ONE GOP spread over the GPUs
+    pair_sharded = None
+    if world > 1 and args.shard == "gops" and args.pair_shard_steps > 0:
+        # A rank that dies or a collective that never completes must not cost the line the driver reads: when the block
+        # has not finished after --pair_shard_timeout_s, rank 0 prints what it has (the timed region and its roofline are
+        # done by now) and every rank leaves without waiting for the others.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["pair_sharded"] = {"error": f"no result within {args.pair_shard_timeout_s} s (watchdog): a rank failed or "
+                                                f"a collective did not complete"}
+                out["bench_wall_s"] = time.time() - t_process
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.pair_shard_timeout_s, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        import pmctf_dist
+        frames0 = frames if rank == 0 else gop_frames(1234)       # every rank reads the same GOP (rank 0's)
+        stats = {}
+
+        def sharded():
+            last["ps"] = pmctf_dist.encode_gop_pair_sharded(net, frames0, H, W, args.q_index, tmp, rank, world, dist,
+                                                            stats=stats)
+        blocks = {}
+        try:
+            with torch.no_grad():
+                t_ps, _ = timed(sharded, args.pair_shard_steps, 1)
+            tt = torch.tensor([t_ps], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_ps = float(tt.item())
+            pair_sharded = {"value": args.gop * args.pair_shard_steps / t_ps, "unit": "frames/s", "scaling": "strong",
+                            "ms_per_step": t_ps / args.pair_shard_steps * 1e3, "steps": args.pair_shard_steps,
+                            "speedup_vs_one_gpu_coding_this_gop": (elapsed / args.steps) / (t_ps / args.pair_shard_steps),
+                            "gather_bytes_per_stage": stats.get("gather_bytes_per_stage"),
+                            "relay_hops": stats.get("relay_hops"), "relay_bytes_per_hop": stats.get("relay_bytes_per_hop"),
+                            "collective": "all_gather_into_tensor (RCCL)" if dist.get_backend() == "nccl" else "all_gather (gloo)",
+                            "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
+                                        "rank, one all-gather of the subband tree per stage",
+                            "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
+            if args.overlap_gops > 1 and world >= 3:     # with two ranks the GOPs would be coded one after the other
+                G2 = args.overlap_gops
+                gops = [frames0] + [gop_frames(1234 + 1000 * k) for k in range(1, G2)]
+                folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_o{k}_") for k in range(1, G2)]
+
+                def overlapped():
+                    last["po"] = pmctf_dist.encode_gops_pair_sharded_overlapped(net, gops, H, W, args.q_index, folders,
+                                                                                rank, world, dist)
+                with torch.no_grad():
+                    t_po, _ = timed(overlapped, max(1, args.pair_shard_steps // 2), 1)
+                tt = torch.tensor([t_po], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                n_po = max(1, args.pair_shard_steps // 2)
+                pair_sharded["overlapped_gops"] = {
+                    "gops_in_flight": G2, "value": G2 * args.gop * n_po / float(tt.item()), "unit": "frames/s",
+                    "ms_per_step": float(tt.item()) / n_po * 1e3, "steps": n_po,
+                    "schedule": f"{G2} closed GOPs interleaved: ranks idle in the late stages of one GOP code the early stages "
+                                f"of the next (SURVEY 8e)",
+                    "bits_identical_to_rank0_gop": (last["po"][0]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
+        except Exception as e:  # noqa: BLE001 - an auxiliary block must never cost the headline line
+            pair_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        watchdog.cancel()
+
+    if rank == 0:
+        if pair_sharded is not None:
+            out["pair_sharded"] = pair_sharded
         # ---- not optional: the CPU baseline -------------------------------------------------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -562,10 +582,17 @@ def main():
         if skipped:
             out["aux_skipped_over_budget"] = skipped
         out["bench_wall_s"] = time.time() - t_process
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        import threading
+        leave = threading.Timer(60.0, lambda: os._exit(0))      # the line is out: never hang on the way out
+        leave.daemon = True
+        leave.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - a rank that left through its watchdog
+            pass
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 #include <string.h>
 #include <mutex>
 #include "pm_device_math.h"
+#include "conv_epilogue.h"
 #include "launch.h"
 #include "../../include/pmctf_hip.h"
 
@@ -125,38 +126,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // epilogue: lane holds couts co..co+3 of pixel (lane&15) of each segment
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int seg = wave * NT + nt;
         const int r = seg / TW16, c16 = seg - r * TW16;
         const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i < a.Cout) {
-                        float s = v[i];
-                        if (a.res1) s = s + a.res1[pbase + co + i];
-                        if (a.res2) s = s + a.res2[pbase + co + i];
-                        a.y[pbase + co + i] = s;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 
@@ -296,38 +280,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int seg = wave * NT + nt;
         const int r = seg / TW16, c16 = seg - r * TW16;
         const int oy = oy0 + r, ox = ox0 + c16 * 16 + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i < a.Cout) {
-                        float s = v[i];
-                        if (a.res1) s = s + a.res1[pbase + co + i];
-                        if (a.res2) s = s + a.res2[pbase + co + i];
-                        a.y[pbase + co + i] = s;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -469,36 +436,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_mfma_wave_kernel(
         if (more) stash(wlds + (NBUF == 2 ? ((cb + 1) & 1) * bufsz : 0));
     }
 
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i < a.Cout) {
-                        float s = v[i];
-                        if (a.res1) s = s + a.res1[pbase + co + i];
-                        if (a.res2) s = s + a.res2[pbase + co + i];
-                        a.y[pbase + co + i] = s;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 
@@ -646,36 +596,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
         if (more) stash(NBUF == 2 ? ((cb + 1) & 1) : 0);
     }
 
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i < a.Cout) {
-                        float s = v[i];
-                        if (a.res1) s = s + a.res1[pbase + co + i];
-                        if (a.res2) s = s + a.res2[pbase + co + i];
-                        a.y[pbase + co + i] = s;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 
@@ -794,34 +727,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    const bool vec = (a.Cout & 3) == 0;
     {
         const int oy = oy0 + wave, ox = ox0 + (lane & 15);
         if (oy < a.oy_end && ox < a.Wo) {
             const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+            PM_EPILOGUE(a,
+_Pragma("unroll")
             for (int mt = 0; mt < MT; ++mt) {
                 const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
                 if (co >= a.Cout) continue;
-                f32x4 v = acc[mt];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-                if (vec) {
-                    if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                    if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                    *(f32x4 *)(a.y + pbase + co) = v;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (co + i < a.Cout) {
-                            float sv = v[i];
-                            if (a.res1) sv = sv + a.res1[pbase + co + i];
-                            if (a.res2) sv = sv + a.res2[pbase + co + i];
-                            a.y[pbase + co + i] = sv;
-                        }
-                    }
-                }
-            }
+                store_frag<ACT, RES>(a, acc[mt], pbase, co);
+            })
         }
     }
 }
@@ -971,36 +887,19 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + (NT == 4 ? 2 * wave + (nt >> 1) : wave), ox = ox0 + 16 * (nt & 1) + (lane & 15);
         if (oy >= a.oy_end || ox >= a.Wo) continue;
         const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (co + i < a.Cout) {
-                        float sv = v[i];
-                        if (a.res1) sv = sv + a.res1[pbase + co + i];
-                        if (a.res2) sv = sv + a.res2[pbase + co + i];
-                        a.y[pbase + co + i] = sv;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 
@@ -1109,31 +1008,14 @@ __global__ __launch_bounds__(256) void conv_mfma_res_kernel(ConvArgs a) {
 
     const int oy = oy0 + wave, ox = ox0 + (lane & 15);
     if (oy >= a.oy_end || ox >= a.Wo) return;
-    const bool vec = (a.Cout & 3) == 0;
     const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int mt = 0; mt < MT; ++mt) {
         const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
         if (co >= a.Cout) continue;
-        f32x4 v = acc[mt];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-        if (vec) {
-            if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-            if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-            *(f32x4 *)(a.y + pbase + co) = v;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (co + i < a.Cout) {
-                    float s = v[i];
-                    if (a.res1) s = s + a.res1[pbase + co + i];
-                    if (a.res2) s = s + a.res2[pbase + co + i];
-                    a.y[pbase + co + i] = s;
-                }
-            }
-        }
-    }
+        store_frag<ACT, RES>(a, acc[mt], pbase, co);
+    })
 }
 
 
@@ -1249,6 +1131,148 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
 }
 
 
+// The same walk at a higher occupancy (round 3): the patch of the NEXT tile waits in registers until the matrix work of
+// the current one has been issued, so ONE wave-private LDS buffer is enough (8.6 KB per wave instead of 17: OCC workgroups
+// per CU instead of two); tiles inside the image take their patch without per-slot bounds tests; and each XCD walks its
+// own contiguous band of tiles, so the halo rows of a tile are found in the L2 that fetched them one round earlier.
+// Same sums, same order.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int tiles_total) {
+    constexpr int NT = 4, LH = 6, LW = 18, E = LH * LW * 4, MAXP = (E + 63) / 64;      // 432 float4 slots, 7 per lane
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int bufsz = LH * LW * CP;
+    float *wlds = lds + wave * bufsz;
+    const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;         // in 4x16 wave tiles
+    const int per_img = tiles_x * tiles_y;
+
+    f32x4 af[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) af[t] = *(const f32x4 *)(a.wp + t * 256 + lane * 4);
+    const f32x4 bias = *(const f32x4 *)(a.bp + 4 * (lane >> 4));
+    const int boff = (lane & 15) * CP + (lane >> 4);
+    const unsigned yoff = ((lane & 15) * 16 + 4 * (lane >> 4)) * 4;       // byte offset of this lane inside a 16-pixel output row
+
+    f32x4 pre[MAXP];
+    unsigned rel[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = lane + 64 * j;
+        const int pix = e >> 2, part = e & 3;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        rel[j] = ((ly * a.W + lx) * 16 + part * 4) * 4;
+    }
+    auto fetch = [&](int tile) {
+        const int n = tile / per_img, r = tile - n * per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy0 = ty * 4 - 1, ix0 = tx * 16 - 1;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + LH <= a.H && ix0 + LW <= a.W) {                      // wave-uniform: inside
+            const char *base = (const char *)a.x + (((long)n * a.H + iy0) * a.W + ix0) * 64;     // scalar
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j)
+                if (j < MAXP - 1 || lane + 64 * j < E) pre[j] = *(const f32x4 *)(base + rel[j]);
+        } else {
+            const char *img = (const char *)a.x + (long)n * a.H * a.W * 64;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                const int e = lane + 64 * j;
+                const int pix = e >> 2;
+                const int ly = pix / LW, lx = pix - ly * LW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < E && (unsigned)(iy0 + ly) < (unsigned)a.H && (unsigned)(ix0 + lx) < (unsigned)a.W)
+                    v = *(const f32x4 *)(img + ((long)(iy0 + ly) * a.W + (ix0 + lx)) * 64 + (e & 3) * 16);
+                pre[j] = v;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int e = lane + 64 * j;
+            if (e < E) {
+                float2 *dst = (float2 *)(wlds + (e >> 2) * CP + (e & 3) * 4);
+                dst[0] = make_float2(pre[j].x, pre[j].y);
+                dst[1] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+    };
+    f32x4 acc[NT];
+    // results of a tile leave one tile later, behind the patch of the next one: the wait for that patch (the newest
+    // vector-memory operations of the wave) then never includes stores that have just been issued
+    auto finish = [&](int tile) {
+        const int n = tile / per_img, r = tile - n * per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const size_t row0 = (((size_t)n * a.Ho + ty * 4) * a.Wo + tx * 16) * 16;          // scalar, in floats
+        if (ty * 4 + NT <= a.Ho && tx * 16 + 16 <= a.Wo && a.act == pm::ACT_NONE && !a.res2) {     // wave-uniform
+            char *yb = (char *)(a.y + row0);
+            if (a.res1) {
+                const char *rb = (const char *)(a.res1 + row0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 r1 = *(const f32x4 *)(rb + (unsigned)(nt * a.Wo * 64) + yoff);
+                    *(f32x4 *)(yb + (unsigned)(nt * a.Wo * 64) + yoff) = acc[nt] + r1;
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) *(f32x4 *)(yb + (unsigned)(nt * a.Wo * 64) + yoff) = acc[nt];
+            }
+            return;
+        }
+        const int ox = tx * 16 + (lane & 15);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = ty * 4 + nt;
+            if (oy < a.Ho && ox < a.Wo) {
+                const size_t o = row0 + (size_t)nt * a.Wo * 16 + (yoff >> 2);
+                f32x4 v = acc[nt];
+                if (a.act == pm::ACT_TANH) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = pm::tanhf_(v[i]);
+                } else if (a.act != pm::ACT_NONE) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
+                }
+                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + o); v = v + r1; }
+                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + o); v = v + r2; }
+                *(f32x4 *)(a.y + o) = v;
+            }
+        }
+    };
+
+    // band of this XCD (workgroups are dealt round-robin to the 8 XCDs; the grid is a multiple of 8)
+    const int xcd = blockIdx.x & 7, wg_in = blockIdx.x >> 3;
+    const int per_xcd = (tiles_total + 7) >> 3;
+    const int t_end = min(tiles_total, (xcd + 1) * per_xcd);
+    const int stride = (gridDim.x >> 3) * WAVES;
+    int tile = xcd * per_xcd + wg_in * WAVES + wave;
+    if (tile >= t_end) return;
+    fetch(tile);
+    int prev = -1;
+    for (; tile < t_end; tile += stride) {
+        stash();
+        if (prev >= 0) finish(prev);
+        if (tile + stride < t_end) fetch(tile + stride);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float *bb = wlds + ((t / 3) * LW + (t % 3)) * CP + boff;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = bb[nt * LW * CP + ks * 4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
+            }
+        }
+        prev = tile;
+    }
+    finish(prev);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 1x1 convolution (stride 1, no padding) as a plain GEMM over the flattened pixels: the MV codec's 192 <-> 768 layers
 // on 72x120 planes and the 64 <-> 256 layers on 576x960.  The tap-oriented kernels above stage a 16-channel chunk per
@@ -1347,36 +1371,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int ti
         __syncthreads();
     }
 
-    const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const long p = p0 + nt * 16 + (lane & 15);
         if (p >= P) continue;
         const size_t pbase = (size_t)p * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int i = 0; i < MTW; ++i) {
             const int co = (t0 + i) * 16 + 4 * (lane >> 4);
             if (!live[i] || co >= a.Cout) continue;
-            f32x4 v = acc[i][nt];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = pm::apply_act(v[k], a.act, a.slope);
-            if (vec) {
-                if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-                if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-                *(f32x4 *)(a.y + pbase + co) = v;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (co + k < a.Cout) {
-                        float sv = v[k];
-                        if (a.res1) sv = sv + a.res1[pbase + co + k];
-                        if (a.res2) sv = sv + a.res2[pbase + co + k];
-                        a.y[pbase + co + k] = sv;
-                    }
-                }
-            }
+            store_frag<ACT, RES>(a, acc[i][nt], pbase, co);
         }
-    }
+    })
 }
 
 
@@ -1397,7 +1404,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"C16_OCC", 2, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1572,6 +1579,17 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
                 long wgs = (tiles + WAVES - 1) / WAVES;
                 const long cap = knob("C16_WGS");
                 if (wgs > cap) wgs = cap;
+                const long occ = knob("C16_OCC");
+                if (occ >= 2) {
+                    long g = ((tiles + WAVES - 1) / WAVES + 7) & ~7L;
+                    if (g > 256 * occ) g = 256 * occ;
+                    const size_t smem1 = (size_t)6 * 18 * CP * sizeof(float) * WAVES;
+                    note_launch("conv16_band_kernel", (int)occ, 1, 1, dim3((unsigned)g));
+                    if (occ == 2) { PM_LAUNCH(conv16_band_kernel<2>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
+                    else if (occ == 3) { PM_LAUNCH(conv16_band_kernel<3>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
+                    else { PM_LAUNCH(conv16_band_kernel<4>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
+                    return pm_launch_status();
+                }
                 const size_t smem = (size_t)6 * 18 * CP * sizeof(float) * 2 * WAVES;
                 note_launch("conv16_persistent_kernel", 1, 1, 1, dim3((unsigned)wgs));
                 PM_LAUNCH(conv16_persistent_kernel, dim3((unsigned)wgs), dim3(256), smem, st, b, (int)tiles);

@@ -25,6 +25,7 @@
 #include <string.h>
 #include <mutex>
 #include "pm_device_math.h"
+#include "conv_epilogue.h"
 #include "launch.h"
 #include "../../include/pmctf_hip.h"
 
@@ -201,23 +202,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_split_kernel(SplitArgs a) 
     }
 
     // ---- epilogue (as conv_mfma.hip): lane holds couts 4g..4g+3 of pixel p of each of its four rows
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
         if (oy >= a.H || ox >= a.W) continue;
         const size_t pbase = (((size_t)n * a.H + oy) * a.W + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mb * MT + mt) * 16 + 4 * g;
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-            if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-            *(f32x4 *)(a.y + pbase + co) = v;
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -345,23 +342,19 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs 
         }
         if (more) stash();       // in-order LDS: after this wave's last read of the chunk
     }
-#pragma unroll
+    PM_EPILOGUE(a,
+_Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
         if (oy >= a.H || ox >= a.W) continue;
         const size_t pbase = (((size_t)n * a.H + oy) * a.W + ox) * a.Cout;
-#pragma unroll
+_Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mb * MT + mt) * 16 + 4 * g;
             if (co >= a.Cout) continue;
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
-            if (a.res1) { const f32x4 r1 = *(const f32x4 *)(a.res1 + pbase + co); v = v + r1; }
-            if (a.res2) { const f32x4 r2 = *(const f32x4 *)(a.res2 + pbase + co); v = v + r2; }
-            *(f32x4 *)(a.y + pbase + co) = v;
+            store_frag<ACT, RES>(a, acc[mt][nt], pbase, co);
         }
-    }
+    })
 }
 
 // cout tiles per M-block / number of M-blocks the kernel is instantiated for
