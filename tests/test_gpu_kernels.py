@@ -40,6 +40,8 @@ CONV_CASES = [
     (1, 16, 64, 64, 16, 3, 1, 1, 3, 0.0, 0),       # PredictUpdate conv2 + tanh
     (2, 16, 150, 203, 16, 3, 1, 1, 3, 0.0, 0),     # persistent 16->16 kernel: ragged tiles, two planes, tanh
     (1, 16, 129, 130, 16, 3, 1, 1, 0, 0.0, 1),     # persistent 16->16 kernel: residual add
+    (1, 16, 130, 141, 16, 3, 1, 1, 2, 0.1, 2),     # persistent 16->16 kernel: leaky, two residual adds, ragged tiles
+    (3, 16, 96, 64, 16, 3, 1, 1, 0, 0.0, 0),       # persistent 16->16 kernel: only whole tiles, three planes (XCD bands)
     (1, 64, 64, 96, 64, 3, 2, 1, 2, 0.01, 0),      # stride-2 3x3
     (1, 64, 64, 96, 64, 1, 2, 0, 0, 0.0, 0),       # stride-2 1x1 (downsample)
     (1, 256, 18, 30, 192, 1, 1, 0, 0, 0.0, 0),     # four-part prior adaptor 1x1 256->192
@@ -172,12 +174,12 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     xd = nhwc(x)
     L = lib.hip()
     defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1,
-                "C16": 1, "C16_WGS": 512, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1, "K33_SMALL": 1}
+                "C16": 1, "C16_WGS": 512, "C16_OCC": 2, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1, "K33_SMALL": 1}
     settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
                 {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}, {"MSPLIT_NT": 2, "MSPLIT_PX": 1 << 40},
-                {"MSPLIT_NT": 4, "MSPLIT_PX": 1 << 40}, {"C16": 0}, {"C16_WGS": 3},
+                {"MSPLIT_NT": 4, "MSPLIT_PX": 1 << 40}, {"C16": 0}, {"C16_WGS": 3}, {"C16_OCC": 0}, {"C16_OCC": 0, "C16_WGS": 3}, {"C16_OCC": 3}, {"C16_OCC": 4},
                 # the shape-specialised kernels against the generic ones
                 {"K33": 0, "NT": 4, "MSPLIT_PX": 0}, {"K33": 0, "NT": 1, "MSPLIT_PX": 0}, {"K77": 0, "NT": 4, "MSPLIT_PX": 0},
                 {"K11": 0}, {"WAVE_SMALL": 0, "MSPLIT_PX": 1 << 40}, {"WAVE_SMALL": 1, "MSPLIT_PX": 1 << 40},
