@@ -162,6 +162,9 @@ class PairPlan:
         bitstream's pinned symbol buffers to the range coder.  Returns the tensors of encode_one_stage's result."""
         A, B = eng.plan_context()["streams"]
         main = torch.cuda.current_stream(eng.dev)
+        if eng.plan_timing is not None:
+            e_begin = torch.cuda.Event(enable_timing=True)
+            e_begin.record(main)
         for dst, src in ((self.in_ry, ry), (self.in_cy, cy), (self.in_rc, rc), (self.in_cc, cc)):
             dst.copy_(src)
         self.g_me.replay()
@@ -215,7 +218,10 @@ class PairPlan:
                 e = mark()
                 e.record(st)
                 e_syn.append(e)
-            eng.plan_timing.append((e_start, e_mv, done[0], done[1], e_syn[0], e_syn[1]))
         main.wait_stream(A)
         main.wait_stream(B)
+        if timing:
+            e_end = mark()
+            e_end.record(main)
+            eng.plan_timing.append((e_start, e_mv, done[0], done[1], e_syn[0], e_syn[1], e_begin, e_end))
         return res

@@ -35,7 +35,10 @@ with torch.no_grad():
 if eng.plan_timing:
     print("per pair, ms after the call's first launch: motion codec done | luma analysis done | chroma analysis done | luma synthesis done | chroma synthesis done")
     for ev in eng.plan_timing[:15]:
-        print("   " + "  ".join(f"{ev[0].elapsed_time(e):7.1f}" for e in ev[1:]))
+        print("   " + "  ".join(f"{ev[0].elapsed_time(e):7.1f}" for e in ev[1:6]) + f"   motion est. {ev[6].elapsed_time(ev[0]):6.1f}")
+    gaps = [a[7].elapsed_time(b[6]) for a, b in zip(eng.plan_timing, eng.plan_timing[1:])]
+    print("GPU idle between the last kernel of a pair and the first of the next (ms):", " ".join(f"{g:.2f}" for g in gaps[:16]),
+          f" total {sum(gaps):.1f} over {len(gaps)} gaps")
 print(f"memory: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, "
       f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; plans {len(eng.pair_plans)}")
 print(f"{G * n / t:.3f} frames/s  ({t / n * 1e3:.1f} ms per GOP)  bits {sum(enc['bits']):.0f}  stats {eng.stats}")
