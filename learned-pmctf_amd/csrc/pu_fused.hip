@@ -148,23 +148,27 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
     __syncthreads();
     PU_STAMP(0);
 
-    // ---- P1 (vector ALU): tanh(conv1) on the 14x38 region.  A thread owns up to three pixels; the 16 couts go in four
-    // groups of four so that a group's 36 weights + 4 biases are wave-uniform scalars while all pixels use them.
+    // ---- P1 (vector ALU): tanh(conv1) on the 14x38 region.  A thread owns two pixels; the 16 couts go in four groups of
+    // four so that a group's 36 weights + 4 biases are wave-uniform scalars while all pixels use them.  The region has
+    // 532 = 2 * 256 + 20 pixels: a third pass over 20 live lanes would cost wave 0 a whole pass (and every other wave
+    // the wait for it), so the 20 left-over pixels are shared out by cout group instead: wave w computes group w of
+    // all of them — a quarter of a pass per wave.
     {
-        constexpr int PPT = (N1 + 255) / 256;
-        float iv[PPT][9];
-        bool ok[PPT];
+        constexpr int PPT = N1 / 256, LEFT = N1 - PPT * 256;
+        static_assert(LEFT >= 0 && LEFT <= 64, "left-over pixels of the conv1 region must fit one wave");
+        float iv[PPT + 1][9];
+        bool ok[PPT + 1];
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int idx = tid + 256 * j;
+        for (int j = 0; j <= PPT; ++j) {
+            const int idx = j < PPT ? tid + 256 * j : PPT * 256 + lane;
+            const bool in_region = j < PPT || lane < LEFT;
             const int r = idx / R1W, c = idx - r * R1W;
             const int gy = y0 - 3 + r, gx = x0 - 3 + c;
-            ok[j] = idx < N1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            ok[j] = in_region && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) iv[j][t] = idx < N1 ? in[(r + t / 3) * IW + c + t % 3] : 0.0f;
+            for (int t = 0; t < 9; ++t) iv[j][t] = in_region ? in[(r + t / 3) * IW + c + t % 3] : 0.0f;
         }
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        auto group = [&](int q, int j, int idx) {
             float wq[4][9], bq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -172,23 +176,24 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) wq[i][t] = a.w1[(q * 4 + i) * 9 + t];
             }
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int idx = tid + 256 * j;
-                if (idx >= N1) continue;
-                float v[4];
+            for (int i = 0; i < 4; ++i) {
+                float acc = bq[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float acc = bq[i];
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[j][t], wq[i][t], acc);
-                    v[i] = ok[j] ? pm::tanhf_(acc) : 0.0f;
-                }
-                float2 *dst = (float2 *)(A1 + idx * CP + 4 * q);
-                dst[0] = make_float2(v[0], v[1]);
-                dst[1] = make_float2(v[2], v[3]);
+                for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[j][t], wq[i][t], acc);
+                v[i] = ok[j] ? pm::tanhf_(acc) : 0.0f;
             }
+            float2 *dst = (float2 *)(A1 + idx * CP + 4 * q);
+            dst[0] = make_float2(v[0], v[1]);
+            dst[1] = make_float2(v[2], v[3]);
+        };
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) group(q, j, tid + 256 * j);
         }
+        if (LEFT > 0 && lane < LEFT) group(wave, PPT, PPT * 256 + lane);
     }
     __syncthreads();
     PU_STAMP(1);
