@@ -219,14 +219,15 @@ def test_rate_points_match_oracle(setup, q_index):
         assert_same(r[k], o[k], f"q_index {q_index}: {k}")
 
 
-def test_full_size_1080p_properties(cuda):
-    """At the benchmark's full size (1920x1080, 4 ME stages) the oracle is too slow, so check what must hold at any
-    size: (1) the decoder reproduces the encoder's reconstruction bit for bit from the written files, (2) the files
-    account for the reported bits, (3) the lifting is inverted by inverse_MCTF up to rounding, (4) coding is
-    deterministic (same bytes twice)."""
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160), (1366, 768)], ids=["1080p", "2160p", "1366x768"])
+def test_full_size_1080p_properties(cuda, size):
+    """At the benchmark's full size (1920x1080, 4 ME stages) — and at four times that, and at a size that is a multiple
+    of nothing the path tiles by — the oracle is too slow, so check what must hold at any size: (1) the decoder
+    reproduces the encoder's reconstruction bit for bit from the written files, (2) the files account for the reported
+    bits, (3) the lifting is inverted by inverse_MCTF up to rounding, (4) coding is deterministic (same bytes twice)."""
     import os
     net, _ = product_model(4)
-    w, h = 1920, 1080
+    w, h = size
     fr = frames(w, h, 2, device="cuda", seed=5)
     dpb = {"mv_feature": None, "ref_mv_y": None}
     with tempfile.TemporaryDirectory() as td:
@@ -244,7 +245,8 @@ def test_full_size_1080p_properties(cuda):
     for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
         assert_same(d[k], e[k], f"1080p decoded {k} vs encoder reconstruction")
         assert_same(e2[k], e[k], f"1080p {k} second run")
-    assert e["H_t"].shape == (1, 1, 1152, 1920) and e["H_tc"].shape == (2, 1, 576, 960)
+    ph, pw = (h + 127) // 128 * 128, (w + 127) // 128 * 128
+    assert e["H_t"].shape == (1, 1, ph, pw) and e["H_tc"].shape == (2, 1, ph // 2, pw // 2)
     # (3) analysis -> synthesis with the coded motion field
     L_t, H_t, _, _ = net.forward_MCTF(fr[0][0], fr[1][0], e["mv_hat"])
     ref, cur = net.inverse_MCTF(L_t, H_t, e["mv_hat"])
