@@ -472,9 +472,10 @@ def test_gop4_960x544_vs_reference(setup):
     assert same >= 9 and diff <= 2, (same, diff)
 
 
-def _digest_path(gop, q_index):
+def _digest_path(gop, q_index, sequence="pan"):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_1920x1080_gop%d_me4%s_digest.npz" % (gop, "" if q_index == 3 else f"_q{q_index}"))
+                        "reference_1920x1080_gop%d_me4%s%s_digest.npz" % (gop, "" if q_index == 3 else f"_q{q_index}",
+                                                                          "" if sequence == "pan" else "_" + sequence))
 
 
 # BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
@@ -489,17 +490,21 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index):
+def _headline_run(gop, q_index, sequence="pan"):
     import hashlib
     import pmctf_gop
-    key = (gop, q_index)
+    key = (gop, q_index, sequence)
     if key in _headline_cache:
         return _headline_cache[key]
-    g = np.load(_digest_path(gop, q_index))
+    g = np.load(_digest_path(gop, q_index, sequence))
     net, _ = product_model(4)
     net.engine().keep_streams = True
     w, h = 1920, 1080
-    fr = frames(w, h, gop, device="cuda")
+    if sequence == "pan":
+        fr = frames(w, h, gop, device="cuda")
+    else:
+        import pmctf_synth
+        fr = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420_layers(w, h, gop)]
     with tempfile.TemporaryDirectory() as td:
         enc = pmctf_gop.encode_gop(net, fr, h, w, q_index, td)
         rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
@@ -523,14 +528,14 @@ def _headline_run(gop, q_index):
            "psnr_err": float(np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max()),
            "same": same, "diff": diff, "lengths_equal": bool(lengths_equal),
            "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
-    print(f"1080p GOP-{gop} q_index {q_index}: bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
+    print(f"1080p GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
           f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
     d = os.environ.get("PMCTF_HEADLINE_REPORT")
     if d:       # builder's measuring run: collect what the pins file is written from
         import json
         os.makedirs(d, exist_ok=True)
         json.dump({k: out[k] for k in ("dbits", "psnr_err", "same", "diff", "lengths_equal", "bpp", "bpp_ref")},
-                  open(os.path.join(d, f"gop{gop}_q{q_index}.json"), "w"))
+                  open(os.path.join(d, f"gop{gop}_q{q_index}{'' if sequence == 'pan' else '_' + sequence}.json"), "w"))
     _headline_cache[key] = out
     del enc, rec, fr
     torch.cuda.empty_cache()
@@ -578,6 +583,20 @@ def test_headline_configs_pinned_deviation(cuda, gop, q_index):
     assert r["dbits"] == pin["dbits"]
     assert abs(r["psnr_err"] - pin["psnr_err"]) < 1e-9
     assert (r["same"], r["diff"]) == (pin["same"], pin["diff"])
+
+
+@pytest.mark.skipif(not os.path.exists(_digest_path(8, 3, "layers")), reason="fixture of the second sequence not generated")
+def test_second_sequence_1080p_gop8_vs_reference(cuda):
+    """The same bar on a SECOND synthetic sequence (pmctf_synth.synth_yuv420_layers: two motion layers, an occluding
+    square — motion boundaries, occlusion and dis-occlusion, which the panning sequence of the headline does not have),
+    1080p GOP 8 q_index 3 against the digest of the real reference's CPU run of it
+    (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 8 --me_stages 4 --sequence layers)."""
+    r = _headline_run(8, 3, "layers")
+    assert r["same"] + r["diff"] == 3 * 7 + 2
+    assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
+    assert r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+    assert r["lengths_equal"]
 
 
 def test_gop_with_reduced_resolution_motion(setup):

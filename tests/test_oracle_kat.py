@@ -65,3 +65,14 @@ def test_reference_ops_cpp_agrees_when_built():
         p = rng.random(n).astype(np.float32) ** 4
         p /= p.sum()
         assert list(m.pmf_to_quantized_cdf(p.tolist(), 16)) == clib.pmf_to_quantized_cdf(p).tolist()
+
+
+def test_synthetic_sequences_are_pinned():
+    """The fixtures under tests/golden/ were written by the real reference on these sequences: the generators must
+    not drift (SHA-1 over the 8-bit planes of five 192x108 frames)."""
+    import hashlib
+    import pmctf_synth
+    for gen, want in ((pmctf_synth.synth_yuv420, "fff11caa60613d9a249bdc4b3a9b71a0da2c3a56"),
+                      (pmctf_synth.synth_yuv420_layers, "058d0de7d26eac2685d9239e858501ed7b2a91db")):
+        frames = gen(192, 108, 5)
+        assert hashlib.sha1(b"".join(p.tobytes() for fr in frames for p in fr)).hexdigest() == want, gen.__name__

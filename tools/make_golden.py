@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--gop", type=int, default=4, help="GOP size of the harness loop")
     ap.add_argument("--me_stages", type=int, default=1, help="num_me_stages of the model")
     ap.add_argument("--q_index", type=int, default=3, help="rate point of the GOP harness loop")
+    ap.add_argument("--sequence", default="pan", choices=["pan", "layers"],
+                    help="synthetic sequence: pmctf_synth.synth_yuv420 (global pan) or synth_yuv420_layers (two motion "
+                         "layers and an occluding square)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -194,7 +197,8 @@ def main():
             "torch": torch.__version__}
 
     W, H = args.width, args.height
-    frames8 = pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234)
+    frames8 = (pmctf_synth.synth_yuv420(W, H, args.gop, seed=1234) if args.sequence == "pan"
+               else pmctf_synth.synth_yuv420_layers(W, H, args.gop))
     frames = [list(pmctf_synth.frames_to_tensors(f)) for f in frames8]
     Y0, C0 = frames[0]
     Y1, C1 = frames[1]
@@ -337,6 +341,8 @@ def main():
     suffix = "" if (args.gop == 4 and args.me_stages == 1) else f"_gop{args.gop}_me{args.me_stages}"
     if args.q_index != 3:
         suffix += f"_q{args.q_index}"
+    if args.sequence != "pan":
+        suffix += "_" + args.sequence
     path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}{suffix}.meta.json"), "w"), indent=1)
