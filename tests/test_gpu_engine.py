@@ -472,10 +472,10 @@ def test_gop4_960x544_vs_reference(setup):
     assert same >= 9 and diff <= 2, (same, diff)
 
 
-def _digest_path(gop, q_index, sequence="pan"):
+def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080)):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_1920x1080_gop%d_me4%s%s_digest.npz" % (gop, "" if q_index == 3 else f"_q{q_index}",
-                                                                          "" if sequence == "pan" else "_" + sequence))
+                        "reference_%dx%d_gop%d_me4%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
+                                                                      "" if sequence == "pan" else "_" + sequence))
 
 
 # BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
@@ -490,16 +490,16 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index, sequence="pan"):
+def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080)):
     import hashlib
     import pmctf_gop
-    key = (gop, q_index, sequence)
+    key = (gop, q_index, sequence, size)
     if key in _headline_cache:
         return _headline_cache[key]
-    g = np.load(_digest_path(gop, q_index, sequence))
+    g = np.load(_digest_path(gop, q_index, sequence, size))
     net, _ = product_model(4)
     net.engine().keep_streams = True
-    w, h = 1920, 1080
+    w, h = size
     if sequence == "pan":
         fr = frames(w, h, gop, device="cuda")
     else:
@@ -528,7 +528,7 @@ def _headline_run(gop, q_index, sequence="pan"):
            "psnr_err": float(np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max()),
            "same": same, "diff": diff, "lengths_equal": bool(lengths_equal),
            "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
-    print(f"1080p GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
+    print(f"{w}x{h} GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
           f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
     d = os.environ.get("PMCTF_HEADLINE_REPORT")
     if d:       # builder's measuring run: collect what the pins file is written from
@@ -593,6 +593,19 @@ def test_second_sequence_1080p_gop8_vs_reference(cuda):
     (tools/make_golden.py --width 1920 --height 1080 --gop_only --gop 8 --me_stages 4 --sequence layers)."""
     r = _headline_run(8, 3, "layers")
     assert r["same"] + r["diff"] == 3 * 7 + 2
+    assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
+    assert r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+    assert r["lengths_equal"]
+
+
+@pytest.mark.skipif(not os.path.exists(_digest_path(2, 3, "layers", (3840, 2160))), reason="4K fixture not generated")
+def test_2160p_pair_vs_reference(cuda):
+    """Largest size: one 3840x2160 pair (H and L coded, four ME stages, q_index 3) of the second sequence against the
+    digest of the real reference's CPU run (tools/make_golden.py --width 3840 --height 2160 --gop_only --digest --gop 2
+    --me_stages 4 --sequence layers): bits identical, PSNR within 1e-4 dB."""
+    r = _headline_run(2, 3, "layers", (3840, 2160))
+    assert r["same"] + r["diff"] == 5
     assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
     assert r["bits_mv"] == r["ref_bits_mv"]
     assert r["psnr_err"] < 1e-4

@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--gop", type=int, default=4, help="GOP size of the harness loop")
     ap.add_argument("--me_stages", type=int, default=1, help="num_me_stages of the model")
     ap.add_argument("--q_index", type=int, default=3, help="rate point of the GOP harness loop")
+    ap.add_argument("--digest", action="store_true", help="file digests instead of tensors also for GOPs of at most 4 frames")
     ap.add_argument("--sequence", default="pan", choices=["pan", "layers"],
                     help="synthetic sequence: pmctf_synth.synth_yuv420 (global pan) or synth_yuv420_layers (two motion "
                          "layers and an occluding square)")
@@ -245,7 +246,7 @@ def main():
 
             def on_pair(stage_idx, i_ref, i_cur, r):
                 files = {}
-                if args.gop_only and args.gop > 4:      # large runs: digests of the files this pair wrote, no tensors
+                if args.gop_only and (args.gop > 4 or args.digest):      # large runs: digests of the files this pair wrote, no tensors
                     names = [f"{i_cur}.bin", f"{i_cur}_mv.bin", f"{i_cur}_C_main.bin"]
                     if r["bit_L"] is not None:
                         names += ["0_main.bin", "0_C_main.bin"]
