@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--pair_shard_timeout_s", type=float, default=240.0,
                     help="watchdog of the `pair_sharded` block: print the line without it when it has not finished by then")
     ap.add_argument("--pair_shard_steps", type=int, default=2, help="steps of the `pair_sharded` block (N > 1; 0 to skip)")
-    ap.add_argument("--overlap_gops", type=int, default=2,
+    ap.add_argument("--overlap_gops", type=int, default=0,
                     help="closed GOPs in flight in the `pair_sharded` block's overlapped variant (SURVEY 8e)")
     args = ap.parse_args()
 
@@ -426,8 +426,10 @@ def main():
                             "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
                                         "rank, one all-gather of the subband tree per stage",
                             "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
-            if args.overlap_gops > 1 and world >= 3:     # with two ranks the GOPs would be coded one after the other
-                G2 = args.overlap_gops
+            # closed GOPs in flight: 0 = as many as keep every rank busy in every stage (N / 2: the late stages of a
+            # GOP-16 have 2 and 1 pairs), at least 2; DESIGN §7 has the expected critical paths
+            G2 = args.overlap_gops if args.overlap_gops > 0 else max(2, world // 2)
+            if G2 > 1 and world >= 3:     # with two ranks the GOPs would be coded one after the other
                 gops = [frames0] + [gop_frames(1234 + 1000 * k) for k in range(1, G2)]
                 folders = [tmp] + [tempfile.mkdtemp(prefix=f"pmctf_bench_r{rank}_o{k}_") for k in range(1, G2)]
 

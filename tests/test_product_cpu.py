@@ -441,7 +441,7 @@ def _overlap_worker(rank, world, port, q, n_gops):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_gops", [(4, 2), (4, 3)])
+@pytest.mark.parametrize("world,n_gops", [(4, 2), (4, 3), (8, 4)])
 def test_pair_sharding_overlapped_gops_gloo(world, n_gops):
     """SURVEY 8e's GOP overlap (pmctf_dist.encode_gops_pair_sharded_overlapped): several closed GOPs in flight over the
     same ranks, their relay chains running in opposite directions so that the late stages land on different ranks.
