@@ -563,7 +563,7 @@ def main():
                 blk = {"value": args.gop * k_p / t_p, "unit": "frames/s", "ms_per_step": t_p / k_p * 1e3, "steps": k_p,
                        "dtype": {"bf16x3": "bf16 x3 split operands, f32 accumulate", "bf16x2": "bf16 x2 split, f32 accumulate",
                                  "bf16": "bf16, f32 accumulate"}.get(prec, prec),
-                       "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px (conv_split.hip); all else exact f32",
+                       "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px, stride 1 and the stride-2 quarter-resolution context convolutions (conv_split.hip); all else exact f32",
                        "schedule": sched_text[args.schedule],
                        "stage_batched": {"value": args.gop * k_p / t_pb, "ms_per_step": t_pb / k_p * 1e3,
                                          "schedule": sched_text["stages"],

@@ -180,6 +180,11 @@ int pmctf_conv3x3_split_pack_weights(const float *w_oihw, const float *bias, int
 int pmctf_conv3x3_split_f32(const float *x, const uint16_t *w_packed, const float *bias_packed, const float *res1,
                             const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int nsplit, int act,
                             float slope, void *stream);
+/* the same arithmetic at stride 2 with explicit geometry (the shape of pmctf_conv2d_nhwc_geom_f32: the quarter-resolution
+ * context convolutions of context_fusion_4step.py:176-191, evaluated only at one parity class); 112 couts */
+int pmctf_conv3x3_split_geom_f32(const float *x, const uint16_t *w_packed, const float *bias_packed, const float *res1,
+                                 const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int nsplit,
+                                 int stride, int pad_h, int pad_w, int Ho, int Wo, int act, float slope, void *stream);
 
 /* The whole PredictUpdate CNN of a lifting step as ONE launch (pu_fused.hip): 1->16, 16->16 tanh, 16->16 (+c1), 16->1,
  * 3x3 zero-padded, with the arithmetic around it.  x / other / out: single-channel planes (N,1,H,W).

@@ -39,6 +39,11 @@ constexpr int THREADS = 512, NWAVES = 8;
 constexpr int PH = 6, PW = 18, NPIX = PH * PW;            // wave patch: 4x16 outputs + 3x3 halo
 constexpr int REGION = 1792;                              // NPIX * 16 B rounded up to a multiple of 256 B
 constexpr int KB_PER_CHUNK = 5;                           // ceil(9 taps / 2)
+// wave patch of the barrier-free kernel at stride S: 4x16 outputs need (3S+3) x (15S+3) input pixels
+constexpr int patch_h(int S) { return 3 * S + 3; }
+constexpr int patch_w(int S) { return 15 * S + 3; }
+constexpr int region_bytes(int S) { return (patch_h(S) * patch_w(S) * 16 + 255) / 256 * 256; }
+static_assert(patch_h(1) == PH && patch_w(1) == PW && region_bytes(1) == REGION, "stride-1 patch");
 
 struct SplitArgs {
     const float *x, *bp, *res1, *res2;
@@ -46,6 +51,7 @@ struct SplitArgs {
     float *y;
     int N, H, W, Cin, Cout, tiles_x, tiles_y, ncb, act;
     float slope;
+    int Ho, Wo, pad_h, pad_w;            // output size and top/left padding (stride 1: H, W, 1, 1)
 };
 
 // partial products kept for NS planes, smallest first: (plane of A, plane of B)
@@ -206,8 +212,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_split_kernel(SplitArgs a) 
 _Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
-        if (oy >= a.H || ox >= a.W) continue;
-        const size_t pbase = (((size_t)n * a.H + oy) * a.W + ox) * a.Cout;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 _Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mb * MT + mt) * 16 + 4 * g;
@@ -223,9 +229,11 @@ _Pragma("unroll")
 // registers, one cout tile ahead of their use: with two waves per SIMD a K block lasts twice its MFMA time, which halves
 // the fragment bandwidth a CU needs (about 31 B/clk for three planes, within L1's 64) — and without barriers the waves
 // drift apart, so one wave's patch staging (fetch, split, LDS writes) hides behind its SIMD partner's MFMAs.
-template <int MT, int NS, int OCC = 2>
+template <int MT, int NS, int OCC = 2, int S = 1>
 __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    // S = 2: the quarter-resolution context convolutions (stride 2, top/left padding 1 - parity: ops.conv_at_class)
+    constexpr int PH = patch_h(S), PW = patch_w(S), NPIX = PH * PW, REGION = region_bytes(S);
     constexpr int PATCH = NS * 2 * REGION;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs 
     const int n = blockIdx.y, mb = blockIdx.z;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int oy0 = ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int iy0 = oy0 * S - a.pad_h, ix0 = ox0 * S - a.pad_w;
 
     f32x4 acc[MT][4];
     {
@@ -300,12 +308,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs 
             int tap = 2 * kb + (g >> 1);
             tap = tap > 8 ? 8 : tap;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const unsigned char *bsrc = patch + (g & 1) * REGION + ((ky * PW) + p + kx) * 16;
+            const unsigned char *bsrc = patch + (g & 1) * REGION + ((ky * PW) + p * S + kx) * 16;
             bf16x8 b[4][NS];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) b[nt][s] = *(const bf16x8 *)(bsrc + s * 2 * REGION + nt * PW * 16);
+                for (int s = 0; s < NS; ++s) b[nt][s] = *(const bf16x8 *)(bsrc + s * 2 * REGION + nt * S * PW * 16);
             if (DEEP) {
                 const long kn = (long)(cb * KB_PER_CHUNK + kb + 1) * MT;       // first fragment group of the next K block
                 const long k0 = kn < wsteps ? kn : 0;
@@ -346,8 +354,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs 
 _Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
-        if (oy >= a.H || ox >= a.W) continue;
-        const size_t pbase = (((size_t)n * a.H + oy) * a.W + ox) * a.Cout;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 _Pragma("unroll")
         for (int mt = 0; mt < MT; ++mt) {
             const int co = (mb * MT + mt) * 16 + 4 * g;
@@ -393,12 +401,21 @@ int launch_split(const SplitArgs &a, int MB, hipStream_t st) {
     return pm_launch_status();
 }
 
-template <int MT, int NS, int OCC = 2>
+template <int MT, int NS, int OCC = 2, int S = 1>
 int launch_split_wave(SplitArgs a, int MB, hipStream_t st) {
-    constexpr size_t smem = (size_t)4 * NS * 2 * REGION;
-    a.tiles_y = (a.H + 7) / 8;                      // 8x32-pixel workgroups of four wave tiles
+    constexpr size_t smem = (size_t)4 * NS * 2 * region_bytes(S);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    if (smem > 64 * 1024) {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void *)conv3x3_split_wave_kernel<MT, NS, OCC, S>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+    }
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + 7) / 8;                     // 8x32-pixel workgroups of four wave tiles
     dim3 grid(a.tiles_x * a.tiles_y, a.N, MB);
-    PM_LAUNCH((conv3x3_split_wave_kernel<MT, NS, OCC>), grid, dim3(256), smem, st, a);
+    PM_LAUNCH((conv3x3_split_wave_kernel<MT, NS, OCC, S>), grid, dim3(256), smem, st, a);
     return pm_launch_status();
 }
 
@@ -488,12 +505,39 @@ extern "C" int pmctf_conv3x3_split_f32(const float *x, const uint16_t *w_packed,
     SplitArgs a;
     a.x = x; a.wp = w_packed; a.bp = bias_packed; a.res1 = res1; a.res2 = res2; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ncb = Cin / 16; a.act = act; a.slope = slope;
+    a.Ho = H; a.Wo = W; a.pad_h = 1; a.pad_w = 1;
     a.tiles_x = (W + 31) / 32;
     a.tiles_y = (H + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
     switch (MT) {
     case 4: return dispatch_ns<4>(a, MB, nsplit, st);
     case 7: return dispatch_ns<7>(a, MB, nsplit, st);
+    default: return PMCTF_EINVAL;
+    }
+}
+
+// Stride-2 form with explicit geometry (the quarter-resolution context convolutions, pmctf_conv2d_nhwc_geom_f32's
+// shape: Ho x Wo outputs, output (oy, ox) reads the 3x3 window whose top-left input pixel is (2 oy - pad_h, 2 ox - pad_w),
+// zeros outside).  Same packed weights as the stride-1 form; barrier-free kernel, one workgroup per CU.
+extern "C" int pmctf_conv3x3_split_geom_f32(const float *x, const uint16_t *w_packed, const float *bias_packed,
+                                            const float *res1, const float *res2, float *y, int N, int H, int W, int Cin,
+                                            int Cout, int nsplit, int stride, int pad_h, int pad_w, int Ho, int Wo,
+                                            int act, float slope, void *stream) {
+    int MT, MB;
+    if (!x || !w_packed || !bias_packed || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 16 ||
+        !split_shape(Cout, MT, MB) || MT != 7 || N > 65535 || stride != 2 || Ho <= 0 || Wo <= 0 || pad_h < 0 ||
+        pad_w < 0 || pad_h > 1 || pad_w > 1 || 2 * (Ho - 1) - pad_h >= H || 2 * (Wo - 1) - pad_w >= W)
+        return PMCTF_EINVAL;
+    SplitArgs a;
+    a.x = x; a.wp = w_packed; a.bp = bias_packed; a.res1 = res1; a.res2 = res2; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ncb = Cin / 16; a.act = act; a.slope = slope;
+    a.Ho = Ho; a.Wo = Wo; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.tiles_x = a.tiles_y = 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nsplit) {
+    case 3: return launch_split_wave<7, 3, 1, 2>(a, MB, st);
+    case 2: return launch_split_wave<7, 2, 1, 2>(a, MB, st);
+    case 1: return launch_split_wave<7, 1, 1, 2>(a, MB, st);
     default: return PMCTF_EINVAL;
     }
 }

@@ -47,6 +47,7 @@ _SIGS = {
     "pmctf_conv3x3_split_packed_size": (i64, [ci, ci, ci]),
     "pmctf_conv3x3_split_pack_weights": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pmctf_conv3x3_split_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
+    "pmctf_conv3x3_split_geom_f32": (ci, [vp] * 6 + [ci] * 12 + [cf, vp]),
     "pmctf_predict_update_fused_f32": (ci, [vp] * 11 + [ci] * 4 + [cf] * 6 + [vp]),
     "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, vp]),
     "pmctf_nearest_up2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, vp]),

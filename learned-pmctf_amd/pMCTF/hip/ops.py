@@ -337,9 +337,15 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H, W,
-                                                     Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2, int(act),
-                                                     float(slope), _stream()), "conv2d_geom")
+    if conv.split and conv.Cout == 112 and y.shape[0] * y.shape[1] * y.shape[2] >= SPLIT_MIN_PX:      # auxiliary profile
+        _lib.check(_lib.hip().pmctf_conv3x3_split_geom_f32(_p(x), C.c_void_p(conv.w16.data_ptr()), _p(conv.b), _p(res1),
+                                                           _p(res2), _p(y), N, H, W, Cin, conv.Cout, conv.split, 2, 1 - py,
+                                                           1 - px, H // 2, W // 2, int(act), float(slope), _stream()),
+                   "conv3x3_split_geom")
+    else:
+        _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H, W,
+                                                         Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2, int(act),
+                                                         float(slope), _stream()), "conv2d_geom")
     if probe is not None:
         e1.record()
         probe["events"].append((e0, e1, 2.0 * y.numel() * Cin * 9))

@@ -245,6 +245,39 @@ def test_split_precision_conv_tracks_the_exact_kernel(cuda, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 112, 44, 70), (2, 112, 18, 36), (1, 32, 100, 66)])
+def test_split_precision_conv_at_parity_class(cuda, shape):
+    """The stride-2 form of the auxiliary kernel (the quarter-resolution context convolutions, ops.conv_at_class): against
+    the exact kernel at the same positions — which itself equals the full convolution sampled at that parity class —
+    for all four classes, with activation and residual, on sizes that do not divide into 8x32 tiles; deterministic."""
+    from pMCTF.hip import ops
+    n, cin, h, w = shape
+    rng = _rng(h * w + cin + 1)
+    wt = torch.from_numpy((rng.standard_normal((112, cin, 3, 3)) * 0.05).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(112).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).cuda()
+    r1 = torch.from_numpy(rng.standard_normal((n, h // 2, w // 2, 112)).astype(np.float32)).cuda()
+    exact_conv = ops.Conv2d(wt, b, 1, (1, 1))
+    full = exact_conv(x)
+    old = ops.SPLIT_MIN_PX
+    ops.SPLIT_MIN_PX = 0
+    try:
+        for cls in range(4):
+            py, px = cls >> 1, cls & 1
+            exact = ops.conv_at_class(exact_conv, x, cls, act=ops.ACT_LEAKY, slope=0.2, res1=r1)
+            assert torch.equal(ops.conv_at_class(exact_conv, x, cls), full[:, py::2, px::2].contiguous())
+            for ns, tol in ((3, 3e-6), (2, 3e-4), (1, 3e-2)):
+                conv = ops.Conv2d(wt, b, 1, (1, 1), split=ns)
+                assert conv.split == ns
+                y = ops.conv_at_class(conv, x, cls, act=ops.ACT_LEAKY, slope=0.2, res1=r1)
+                err = (y - exact).abs().max().item() / exact.abs().max().item()
+                assert 0 < err < tol, (cls, ns, err)          # > 0: the split kernel really ran
+                assert torch.equal(y, ops.conv_at_class(conv, x, cls, act=ops.ACT_LEAKY, slope=0.2, res1=r1))
+    finally:
+        ops.SPLIT_MIN_PX = old
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 6, 9, 4), (3, 64, 6, 10), (1, 3, 4, 4)])
 def test_nearest_up2_and_pixel_shuffle2_are_exact_copies(cuda, shape):
     """nearest x2 upsampling and nn.PixelShuffle(2) on NHWC (scalar and 16-byte forms: C % 4 == 0 or not) against the torch
