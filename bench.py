@@ -25,7 +25,9 @@ and, while the wall-clock budget for auxiliary legs (--aux_budget_s) lasts:
 N GPUs encode N independent GOPs (closed GOPs are independent units: no data-path collective; weak scaling) — that is
 `value`; with N > 1 the same ranks then time the north-star layout as `pair_sharded`: ONE GOP, the pairs of each
 temporal stage spread over the ranks, motion context relayed rank to rank, one all-gather of the subband tree per
-stage over RCCL (strong scaling).
+stage over RCCL (strong scaling), alone and — from three ranks on — with max(2, N/2) closed GOPs in flight.
+That block runs after the timed region and its roofline pass and under a watchdog (--pair_shard_timeout_s): a rank that
+dies or a collective that never completes costs the block, never the line.
 Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
