@@ -98,9 +98,20 @@ class PairPlan:
         L = _lib.hip()
         split_knob = L.pmctf_conv2d_get_option(b"SPLIT")
         L.pmctf_conv2d_set_option(b"SPLIT", int(os.environ.get("PMCTF_PLAN_SPLIT", "0")))
+        # No finaliser may run while a capture is open: the launch plans of a model that has been dropped are destroyed
+        # when the cyclic collector finds them (an engine outlives its model as unreachable garbage), and destroying HIP
+        # graphs / returning their pools inside another capture ends the process.  Collect them NOW, keep the collector
+        # off until the last graph of this plan is closed.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        torch.cuda.synchronize(dev)
+        gc.disable()
         try:
             self._record(eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample)
         finally:
+            if gc_was_on:
+                gc.enable()
             L.pmctf_conv2d_set_option(b"SPLIT", split_knob)
 
     def _record(self, eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample):

@@ -150,6 +150,15 @@ class pMCTF(nn.Module):
             self._engine.release()
         self._engine = None
 
+    def __del__(self):
+        # the engine's launch plans hold device memory pools: give them back when the model goes, not when the cyclic
+        # collector gets round to the engine (which may be in the middle of another model's stream capture)
+        try:
+            if getattr(self, "_engine", None) is not None:
+                self._drop_engine()
+        except Exception:  # noqa: BLE001 - interpreter shutdown, device already gone
+            pass
+
     def engine(self):
         if self._engine is not None and self._engine.precision != self.precision:
             self._drop_engine()
