@@ -585,7 +585,7 @@ def test_headline_configs_pinned_deviation(cuda, gop, q_index):
     assert (r["same"], r["diff"]) == (pin["same"], pin["diff"])
 
 
-SECOND_CONFIGS = [(g, q) for g, q in ((8, 3), (8, 0), (8, 8), (8, 12), (8, 20), (16, 3))
+SECOND_CONFIGS = [(g, q) for g, q in ((8, 3), (8, 0), (8, 4), (8, 8), (8, 12), (8, 16), (8, 20), (16, 3))
                   if os.path.exists(_digest_path(g, q, "layers"))]
 SECOND_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "second_sequence_pins.json")
 
