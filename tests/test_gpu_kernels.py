@@ -92,6 +92,58 @@ def test_conv2d_bitexact(cuda, case):
     assert_same(nchw(y), ref, f"conv {case}")
 
 
+def _random_conv_cases(seed, count):
+    """Seeded draw over everything the conv entry points accept: channel counts on and off the 16-channel chunk, filters
+    1/3/5/7 (5x5 only exists on the generic kernels), strides 1-3, 'same' / 'valid' / asymmetric padding, planes smaller
+    than one tile and smaller than the filter's reach, 1-3 planes, every activation, 0-2 residual adds."""
+    r = _rng(seed)
+    cases = []
+    while len(cases) < count:
+        cin = int(r.choice([1, 2, 3, 4, 8, 12, 16, 20, 32, 48, 64, 80, 112, 128, 192]))
+        cout = int(r.choice([1, 2, 3, 5, 16, 17, 24, 32, 40, 64, 96, 112, 128, 192, 256]))
+        k = int(r.choice([1, 3, 3, 3, 5, 7]))
+        s = int(r.choice([1, 1, 1, 2, 3]))
+        ph, pw = (int(v) for v in r.choice([0, k // 2, k // 2, k - 1], size=2))
+        n = int(r.choice([1, 1, 2, 3]))
+        h, w = int(r.integers(max(1, k - 2 * ph), 70)), int(r.integers(max(1, k - 2 * pw), 90))
+        if cin * cout * k * k * 4 > 64 * 1024 and cin <= 4:
+            continue                                    # the small-cin kernel keeps its filter in 64 KB of LDS
+        cases.append((n, cin, h, w, cout, k, s, ph, pw, int(r.integers(0, 5)), float(r.choice([0.0, 0.01, 0.2])),
+                      int(r.integers(0, 3))))
+    return cases
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_conv2d_random_shapes_bitexact(cuda, seed):
+    """Fuzz of pmctf_conv2d_nhwc_f32 / _smallcin_f32 / _fewcout_f32 behind ops.Conv2d against the oracle's C convolution:
+    whatever kernel variant the dispatcher picks for a shape, the bits are PM-F32's."""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    for case in _random_conv_cases(seed, 24):
+        n, cin, h, w_, cout, k, s, ph, pw, act, slope, nres = case
+        r = _rng(seed * 1000 + cin + cout + h)
+        x = r.standard_normal((n, cin, h, w_), dtype=np.float32) * 2
+        wt = (r.standard_normal((cout, cin, k, k), dtype=np.float32) * 0.1).astype(np.float32)
+        b = r.standard_normal(cout, dtype=np.float32)
+        ref = clib.conv2d(x, wt, b, s, (ph, pw))
+        if act == 1:
+            ref = np.maximum(ref, 0)
+        elif act == 2:
+            ref = np.where(ref > 0, ref, ref * np.float32(slope)).astype(np.float32)
+        elif act == 3:
+            ref = clib.tanh(ref)
+        elif act == 4:
+            ref = clib.sigmoid(ref)
+        res = [r.standard_normal(ref.shape, dtype=np.float32) for _ in range(nres)]
+        for q in res:
+            ref = ref + q
+        conv = ops.Conv2d(torch.from_numpy(wt), torch.from_numpy(b), s, (ph, pw))
+        y = conv(nhwc(x), act=act, slope=slope, res1=nhwc(res[0]) if nres > 0 else None,
+                 res2=nhwc(res[1]) if nres > 1 else None)
+        torch.cuda.synchronize()
+        assert_same(nchw(y), ref, f"conv (N, Cin, H, W, Cout, K, S, pad_h, pad_w, act, slope, nres) = {case}")
+
+
 def test_conv2d_denormals_and_specials(cuda):
     """MFMA f32 must behave as an fmaf chain also on subnormal products / tiny accumulators."""
     from pmctf_oracle import clib
