@@ -21,6 +21,8 @@ and, while the wall-clock budget for auxiliary legs (--aux_budget_s) lasts:
   * `stage_batched`     — all pairs of a temporal stage in one call (pMCTF.encode_stage_pairs);
   * `cross_gop_batched` — the same with stage s of K closed GOPs in one call (pmctf_gop.encode_gops_batched);
   * `decode_pair`       — one 1080p pair with skip_decoding=False: the real decoder's time;
+  * `hbm_kernels`       — the bandwidth-bound kernels of the path (warp, lifting add, depthwise, few-channel convolutions,
+                          resampling) on their 1080p shapes: algorithmic GB/s against the 8 TB/s HBM peak;
   * `aux_profiles`      — the reduced-precision arithmetic profiles (no parity claim).
 N GPUs encode N independent GOPs (closed GOPs are independent units: no data-path collective; weak scaling) — that is
 `value`; with N > 1 the same ranks then time the north-star layout as `pair_sharded`: ONE GOP, the pairs of each
@@ -541,6 +543,20 @@ def main():
                                           schedule="encode_one_stage(skip_decoding=False): decompress_mv + decompress_one_stage "
                                                    "of luma and chroma; the sequential LL subband decodes inside one persistent kernel")
             optional("decode_pair", decode_pair)
+
+            def hbm_kernels():
+                # the bandwidth-bound kernels of the path (warp, lifting add, depthwise, few-channel convs, resampling) on
+                # their 1080p shapes: algorithmic bytes / HIP-event time against the 8 TB/s HBM3E peak (tools/bench_hbm.py)
+                import contextlib
+                import io
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_hbm
+                with contextlib.redirect_stdout(io.StringIO()):
+                    rows = bench_hbm.main()
+                out["hbm_kernels"] = {"peak_GBps": bench_hbm.PEAK, "rows": [
+                    {"kernel": n, "us": round(t * 1e6, 1), "algorithmic_MB": round(b / 1e6, 1),
+                     "GBps": round(b / t / 1e9), "frac_of_hbm_peak": round(b / t / 1e9 / bench_hbm.PEAK, 3)} for n, t, b in rows]}
+            optional("hbm_kernels", hbm_kernels)
         if aux and args.aux_precisions:
             # AUXILIARY arithmetic profiles (second conv variant): the dense 3x3 convolutions on bf16 MFMA
             # with operands split into 3 / 2 / 1 planes.  Reported beside the exact figure, never instead of it, with what

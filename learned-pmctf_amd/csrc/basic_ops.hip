@@ -33,11 +33,11 @@ __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *_
     __syncthreads();
     const long total = (long)N * Ho * Wo * Cout;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % Cout);
-        long p = idx / Cout;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+        const int co = (int)(pm_mod(idx, Cout));
+        long p = pm_div(idx, Cout);
+        const int ox = (int)(pm_mod(p, Wo)); p = pm_div(p, Wo);
+        const int oy = (int)(pm_mod(p, Ho));
+        const int n = (int)(pm_div(p, Ho));
         float acc = bias ? bias[co] : 0.0f;
         for (int ky = 0; ky < KH; ++ky) {
             const int iy = oy * S + ky - ph;
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
                                            w[((co + 2) * CIN + ci) * 9 + t], w[((co + 3) * CIN + ci) * 9 + t]);
     const float4 b = bias ? *(const float4 *)(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (long item = (long)blockIdx.x * 4 + wave; item < total_items; item += (long)gridDim.x * 4) {
-        const int ws = (int)(item % wstrips_per_row);
-        const long r = item / wstrips_per_row;
-        const int oy = (int)(r % H);
-        const int n = (int)(r / H);
+        const int ws = (int)(pm_mod(item, wstrips_per_row));
+        const long r = pm_div(item, wstrips_per_row);
+        const int oy = (int)(pm_mod(r, H));
+        const int n = (int)(pm_div(r, H));
         const int sx = (ws * G + g) * P;
         if (!active || sx >= W) continue;
         float in[3][P + 2][CIN];
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__
                                                                  int N, int H, int W, int act2, float slope) {
     const long total = (long)N * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % W);
-        const long r = idx / W;
-        const int oy = (int)(r % H);
+        const int ox = (int)(pm_mod(idx, W));
+        const long r = pm_div(idx, W);
+        const int oy = (int)(pm_mod(r, H));
         const float *plane = x + (r - oy) * W;           // start of image n
         float in[9];
 #pragma unroll
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__re
     constexpr int P = K / 2;
     const long total = (long)N * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % W);
-        const long r = idx / W;
-        const int oy = (int)(r % H);
+        const int ox = (int)(pm_mod(idx, W));
+        const long r = pm_div(idx, W);
+        const int oy = (int)(pm_mod(r, H));
         const float *img = x + (r - oy) * W * CIN;
         float acc[CO];
 #pragma unroll
@@ -375,11 +375,11 @@ __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restri
     const int pad = K / 2;
     const long total = (long)N * H * W * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        long p = idx / C;
-        const int ox = (int)(p % W); p /= W;
-        const int oy = (int)(p % H);
-        const int n = (int)(p / H);
+        const int c = (int)(pm_mod(idx, C));
+        long p = pm_div(idx, C);
+        const int ox = (int)(pm_mod(p, W)); p = pm_div(p, W);
+        const int oy = (int)(pm_mod(p, H));
+        const int n = (int)(pm_div(p, H));
         float acc = bias ? bias[c] : 0.0f;
         for (int ky = 0; ky < K; ++ky) {
             const int iy = oy + ky - pad;
@@ -405,12 +405,12 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const float *__restr
     const int strips = (W + PX - 1) / PX;
     const long total = (long)N * H * strips * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4) * 4;
-        long r = idx / C4;
-        const int sx = (int)(r % strips) * PX;
+        const int c = (int)(pm_mod(idx, C4)) * 4;
+        long r = pm_div(idx, C4);
+        const int sx = (int)(pm_mod(r, strips)) * PX;
         r /= strips;
-        const int oy = (int)(r % H);
-        const long n = r / H;
+        const int oy = (int)(pm_mod(r, H));
+        const long n = pm_div(r, H);
         float4 wr[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -460,12 +460,12 @@ __global__ __launch_bounds__(256) void dwconv3_column_kernel(const float *__rest
     const int strips = (W + PX - 1) / PX, bands = (H + RY - 1) / RY;
     const long total = (long)N * bands * strips * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4) * 4;
-        long r = idx / C4;
-        const int sx = (int)(r % strips) * PX;
+        const int c = (int)(pm_mod(idx, C4)) * 4;
+        long r = pm_div(idx, C4);
+        const int sx = (int)(pm_mod(r, strips)) * PX;
         r /= strips;
-        const int oy0 = (int)(r % bands) * RY;
-        const long n = r / bands;
+        const int oy0 = (int)(pm_mod(r, bands)) * RY;
+        const long n = pm_div(r, bands);
         float4 wr[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -524,9 +524,9 @@ __global__ void flow_warp_kernel(const float *__restrict__ im, const float *__re
     const float cx = (float)(W - 1) / 2.0f, cy = (float)(H - 1) / 2.0f;
     const float mx = (float)(W - 1), my = (float)(H - 1);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / HW);
+        const int n = (int)(pm_div(idx, HW));
         const long p = idx - (long)n * HW;
-        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        const int y = (int)(pm_div(p, W)), x = (int)(p - (long)y * W);
         const float *f = flow + (flowN == 1 ? 0 : (long)n * 2 * HW);
         const float fx = sign * f[p], fy = sign * f[HW + p];
         const float gx = lin_x[x] + fx / cx;
@@ -561,10 +561,10 @@ __global__ void avgpool2_kernel(const float *__restrict__ x, float *y, int NC, i
     const int Ho = H / 2, Wo = W / 2;
     const long total = (long)NC * Ho * Wo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % Wo);
-        long p = idx / Wo;
-        const int oy = (int)(p % Ho);
-        const long nc = p / Ho;
+        const int ox = (int)(pm_mod(idx, Wo));
+        long p = pm_div(idx, Wo);
+        const int oy = (int)(pm_mod(p, Ho));
+        const long nc = pm_div(p, Ho);
         const float *r0 = x + (nc * H + 2 * oy) * W + 2 * ox;
         const float *r1 = r0 + W;
         float s = r0[0] + r0[1];
@@ -594,10 +594,10 @@ __global__ void bilinear_up_kernel(const float *__restrict__ x, float *y, int NC
     const float rf = 1.0f / (float)f;
     const long total = (long)NC * Ho * Wo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % Wo);
-        long p = idx / Wo;
-        const int oy = (int)(p % Ho);
-        const long nc = p / Ho;
+        const int ox = (int)(pm_mod(idx, Wo));
+        long p = pm_div(idx, Wo);
+        const int oy = (int)(pm_mod(p, Ho));
+        const long nc = pm_div(p, Ho);
         int x0, x1, y0, y1;
         float lx0, lx1, ly0, ly1;
         up_coef(ox, W, rf, x0, x1, lx0, lx1);
@@ -614,10 +614,10 @@ __global__ void bilinear_down_kernel(const float *__restrict__ x, float *y, int 
     const int Ho = H / f, Wo = W / f, c = f / 2 - 1;
     const long total = (long)NC * Ho * Wo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % Wo);
-        long p = idx / Wo;
-        const int oy = (int)(p % Ho);
-        const long nc = p / Ho;
+        const int ox = (int)(pm_mod(idx, Wo));
+        long p = pm_div(idx, Wo);
+        const int oy = (int)(pm_mod(p, Ho));
+        const long nc = pm_div(p, Ho);
         const float *r0 = x + (nc * H + f * oy + c) * W + f * ox + c;
         const float *r1 = r0 + W;
         const float t0 = r0[0] * 0.5f + r0[1] * 0.5f;

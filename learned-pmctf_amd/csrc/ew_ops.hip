@@ -42,12 +42,14 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
     }
 }
 
-template <bool CFAST>
+// IT = int when the element count fits 31 bits (every plane of the path): 64-bit integer division costs several times
+// the 32-bit one and the index split is most of this kernel's instructions.
+template <bool CFAST, typename IT>
 __global__ void ew_kernel(int op, float *out, View vo, const float *a, View va, const float *b, View vb, int N, int C,
                           int H, int W, float alpha, float beta) {
     const long total = (long)N * C * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        long r = idx;
+        IT r = (IT)idx;
         int n, c, h, w;
         if (CFAST) { c = (int)(r % C); r /= C; w = (int)(r % W); r /= W; h = (int)(r % H); n = (int)(r / H); }
         else { w = (int)(r % W); r /= W; h = (int)(r % H); r /= H; c = (int)(r % C); n = (int)(r / C); }
@@ -55,6 +57,44 @@ __global__ void ew_kernel(int op, float *out, View vo, const float *a, View va, 
         const float bv = b ? b[n * vb.s[0] + c * vb.s[1] + h * vb.s[2] + w * vb.s[3]] : 0.0f;
         out[n * vo.s[0] + c * vo.s[1] + h * vo.s[2] + w * vo.s[3]] = ew_apply(op, av, bv, alpha, beta);
     }
+}
+
+// All operands dense with the same strides (whole planes, whole NHWC / NCHW tensors): the op is a flat map over `total`
+// consecutive floats, whatever the logical order — no index arithmetic, 16-byte accesses.  Same ew_apply per element.
+template <bool VEC>
+__global__ void ew_flat_kernel(int op, float *out, const float *a, const float *b, long total, float alpha, float beta) {
+    if (VEC) {
+        const long total4 = total >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+            const float4 av = ((const float4 *)a)[i];
+            const float4 bv = b ? ((const float4 *)b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = ew_apply(op, av.x, bv.x, alpha, beta);
+            o.y = ew_apply(op, av.y, bv.y, alpha, beta);
+            o.z = ew_apply(op, av.z, bv.z, alpha, beta);
+            o.w = ew_apply(op, av.w, bv.w, alpha, beta);
+            ((float4 *)out)[i] = o;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+            out[i] = ew_apply(op, a[i], b ? b[i] : 0.0f, alpha, beta);
+    }
+}
+
+// strides of a dense tensor over dims d (any dimension order; size-1 dimensions may carry any stride)?
+inline bool dense_strides(const long *s, const int *d) {
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j)
+            if (s[order[j]] < s[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    long expect = 1;
+    for (int i = 0; i < 4; ++i) {
+        const int k = order[i];
+        if (d[k] == 1) continue;
+        if (s[k] != expect) return false;
+        expect *= d[k];
+    }
+    return true;
 }
 
 // SpyNet level input: [im1 x3, warp x3, flow_up x2] -> NHWC 8 channels (video_net.py:116-119; the three image
@@ -75,10 +115,10 @@ __global__ void lift_skip3_kernel(const float *__restrict__ x, float *y, int NC,
                                   float w2, float bias) {
     const long total = (long)NC * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int xw = (int)(idx % W);
-        long r = idx / W;
-        const int yy = (int)(r % H);
-        const long nc = r / H;
+        const int xw = (int)(pm_mod(idx, W));
+        long r = pm_div(idx, W);
+        const int yy = (int)(pm_mod(r, H));
+        const long nc = pm_div(r, H);
         const int ym = yy == 0 ? 1 : yy - 1;
         const int yp = yy == H - 1 ? H - 2 : yy + 1;
         const float *pl = x + nc * H * W;
@@ -93,11 +133,11 @@ __global__ void lift_skip3_kernel(const float *__restrict__ x, float *y, int NC,
 __global__ void nearest_up2_kernel(const float *__restrict__ x, float *y, int N, int H, int W, int C) {
     const long total = (long)N * 2 * H * 2 * W * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        long r = idx / C;
-        const int ox = (int)(r % (2 * W)); r /= 2 * W;
-        const int oy = (int)(r % (2 * H));
-        const int n = (int)(r / (2 * H));
+        const int c = (int)(pm_mod(idx, C));
+        long r = pm_div(idx, C);
+        const int ox = (int)(pm_mod(r, (2 * W))); r = pm_div(r, 2 * W);
+        const int oy = (int)(pm_mod(r, (2 * H)));
+        const int n = (int)(pm_div(r, (2 * H)));
         y[idx] = x[(((long)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
     }
 }
@@ -107,11 +147,11 @@ __global__ void pixel_shuffle2_kernel(const float *__restrict__ x, float *y, int
                                       float slope) {
     const long total = (long)N * 2 * H * 2 * W * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        long r = idx / C;
-        const int ox = (int)(r % (2 * W)); r /= 2 * W;
-        const int oy = (int)(r % (2 * H));
-        const int n = (int)(r / (2 * H));
+        const int c = (int)(pm_mod(idx, C));
+        long r = pm_div(idx, C);
+        const int ox = (int)(pm_mod(r, (2 * W))); r = pm_div(r, 2 * W);
+        const int oy = (int)(pm_mod(r, (2 * H)));
+        const int n = (int)(pm_div(r, (2 * H)));
         const float v = x[(((long)n * H + (oy >> 1)) * W + (ox >> 1)) * (4 * C) + c * 4 + (oy & 1) * 2 + (ox & 1)];
         y[idx] = pm::apply_act(v, act, slope);
     }
@@ -123,11 +163,11 @@ __global__ __launch_bounds__(256) void nearest_up2_vec4_kernel(const float *__re
     const int C4 = C >> 2;
     const long total = (long)N * H * W * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4) * 4;
-        long r = idx / C4;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H);
-        const long n = r / H;
+        const int c = (int)(pm_mod(idx, C4)) * 4;
+        long r = pm_div(idx, C4);
+        const int w = (int)(pm_mod(r, W)); r = pm_div(r, W);
+        const int h = (int)(pm_mod(r, H));
+        const long n = pm_div(r, H);
         const float4 v = *(const float4 *)(x + ((n * H + h) * W + w) * C + c);
         float *o = y + ((n * 2 * H + 2 * h) * (2L * W) + 2 * w) * C + c;
         *(float4 *)o = v;
@@ -142,11 +182,11 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *_
     const int C4 = C >> 2;
     const long total = (long)N * H * W * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C4) * 4;                       // output channels c .. c+3 = input channels 4c .. 4c+15
-        long r = idx / C4;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H);
-        const long n = r / H;
+        const int c = (int)(pm_mod(idx, C4)) * 4;                       // output channels c .. c+3 = input channels 4c .. 4c+15
+        long r = pm_div(idx, C4);
+        const int w = (int)(pm_mod(r, W)); r = pm_div(r, W);
+        const int h = (int)(pm_mod(r, H));
+        const long n = pm_div(r, H);
         const float4 *p = (const float4 *)(x + ((n * H + h) * W + w) * (4L * C) + 4 * c);
         float4 q[4];                                             // q[k] = input channels of output channel c+k: (i,j) = x,y,z,w
 #pragma unroll
@@ -169,8 +209,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *_
 __global__ void ffn3_mix_kernel(const float *__restrict__ x, float *y, long P, int C) {
     const long total = P * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long p = idx / C;
+        const int c = (int)(pm_mod(idx, C));
+        const long p = pm_div(idx, C);
         const float x1 = x[p * 2 * C + c], x2 = x[p * 2 * C + C + c];
         const float a = x1 > 0.0f ? x1 : x1 * 0.1f;
         const float b = x2 > 0.0f ? x2 : x2 * 0.01f;
@@ -183,8 +223,8 @@ __global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__r
                                   float *hid_out, long P, int C, int Cc) {
     const long total = P * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const long p = idx / C;
+        const int c = (int)(pm_mod(idx, C));
+        const long p = pm_div(idx, C);
         const float v = xh[idx];
         const float g = pm::sigmoidf_(v);
         const float ct = pm::tanhf_(v);
@@ -219,11 +259,11 @@ __global__ void fourstep_quant_kernel(const float *__restrict__ x, const float *
                                       float step) {
     const long total = (long)N * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int xw = (int)(i % W);
-        const int yy = (int)((i / W) % H);
+        const int xw = (int)(pm_mod(i, W));
+        const int yy = (int)pm_mod(pm_div(i, W), H);
         const int cls = (yy & 1) * 2 + (xw & 1);
         if (cls == k) {
-            const long pi = psub ? ((i / ((long)W * H)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xw >> 1) : i;
+            const long pi = psub ? ((pm_div(i, ((long)W * H))) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xw >> 1) : i;
             const float scale = params[pi * 2], mean = params[pi * 2 + 1];
             const float res = x[i] - mean;
             const float q = __builtin_rintf(res);
@@ -244,7 +284,7 @@ __global__ void ll_quant_kernel(const float *__restrict__ ll, const float *__res
                                 short *sym, short *idx, long total, int planes, float lmin, float step) {
     const long npos = planes > 0 ? total / planes : total;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long o = planes > 0 ? (i % npos) * planes + i / npos : i;     // position-major for the sequential coder
+        const long o = planes > 0 ? (pm_mod(i, npos)) * planes + pm_div(i, npos) : i;     // position-major for the sequential coder
         const float scale = params[i * 2], mean = params[i * 2 + 1];
         const float res = __builtin_rintf(ll[i]) - mean;
         const float q = __builtin_rintf(res);
@@ -258,8 +298,8 @@ __global__ void ll_quant_kernel(const float *__restrict__ ll, const float *__res
 __global__ void z_symbols_kernel(const float *__restrict__ z, float *z_hat, short *sym, short *idx, int HW, int C) {
     const long total = (long)HW * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long p = i / C;
+        const int c = (int)(pm_mod(i, C));
+        const long p = pm_div(i, C);
         const float q = __builtin_rintf(z[i]);
         z_hat[i] = q;
         sym[(long)c * HW + p] = sym16(q);
@@ -280,7 +320,7 @@ __global__ void mv_fourpart_kernel(const float *__restrict__ y, const float *__r
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i & 63);
         const long p = i >> 6;
-        const int xw = (int)(p % W), yy = (int)(p / W);
+        const int xw = (int)(pm_mod(p, W)), yy = (int)(pm_div(p, W));
         const int cls = (yy & 1) * 2 + (xw & 1);
         const int g = c >> 4, cc = c & 15;
         if (MV_PERM[t][g] == cls) {
@@ -324,12 +364,29 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
     View vo, va, vb;
     for (int i = 0; i < 4; ++i) { vo.s[i] = so[i]; va.s[i] = sa[i]; vb.s[i] = (b && sb) ? sb[i] : 0; }
     const long total = (long)N * C * H * W;
-    if (cfast)
-        PM_LAUNCH(ew_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
-                           b, vb, N, C, H, W, alpha, beta);
-    else
-        PM_LAUNCH(ew_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, op, out, vo, a, va,
-                           b, vb, N, C, H, W, alpha, beta);
+    hipStream_t st = (hipStream_t)stream;
+    {   // flat form: every operand dense with the output's strides (size-1 dimensions do not matter)
+        const int d[4] = {N, C, H, W};
+        bool same = (b == nullptr) || (sb != nullptr);
+        for (int i = 0; i < 4 && same; ++i)
+            if (d[i] != 1 && (va.s[i] != vo.s[i] || (b && vb.s[i] != vo.s[i]))) same = false;
+        if (same && dense_strides(vo.s, d)) {
+            const bool vec = (total & 3) == 0 && (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) & 15) == 0;
+            if (vec)
+                PM_LAUNCH(ew_flat_kernel<true>, dim3(grid_for(total >> 2)), dim3(256), 0, st, op, out, a, b, total, alpha, beta);
+            else
+                PM_LAUNCH(ew_flat_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, op, out, a, b, total, alpha, beta);
+            return launch_ok();
+        }
+    }
+    const bool small = total < (1L << 31);
+    if (cfast) {
+        if (small) PM_LAUNCH((ew_kernel<true, int>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
+        else PM_LAUNCH((ew_kernel<true, long>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
+    } else {
+        if (small) PM_LAUNCH((ew_kernel<false, int>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
+        else PM_LAUNCH((ew_kernel<false, long>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
+    }
     return launch_ok();
 }
 

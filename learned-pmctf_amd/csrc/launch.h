@@ -17,3 +17,15 @@ static inline int pm_launch_status() {
     fprintf(stderr, "libpmctf_hip: kernel launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
     return -2;
 }
+
+// Flat indices of the elementwise / few-channel kernels are non-negative and, for every plane of the path, below 2^31:
+// divide on 32 bits whenever both operands fit.  A 64-bit integer division is an emulated sequence of about a hundred
+// vector-ALU instructions, which made kernels with a handful of instructions per element ALU-bound instead of
+// HBM-bound (tools/bench_hbm.py: plane add 12.3 us against 3.9 us for a copy of the same bytes).  The branch is
+// uniform over a launch in practice.
+__device__ __forceinline__ long pm_div(long x, long d) {
+    return ((x | d) >> 31) == 0 ? (long)((unsigned)x / (unsigned)d) : x / d;
+}
+__device__ __forceinline__ long pm_mod(long x, long d) {
+    return ((x | d) >> 31) == 0 ? (long)((unsigned)x % (unsigned)d) : x % d;
+}

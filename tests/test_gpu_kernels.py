@@ -345,3 +345,67 @@ def test_nearest_up2_and_pixel_shuffle2_are_exact_copies(cuda, shape):
     assert_same(nchw(ps), F.pixel_shuffle(torch.from_numpy(x4), 2).numpy(), "pixel_shuffle2")
     ps = ops.pixel_shuffle2(nhwc(x4), act=ops.ACT_LEAKY, slope=0.1)
     assert_same(nchw(ps), F.leaky_relu(F.pixel_shuffle(torch.from_numpy(x4), 2), 0.1).numpy(), "pixel_shuffle2 + leaky")
+
+
+def _ew_expected(op, a, b, alpha, beta, ops):
+    """numpy float32 restatement of ew_apply (one rounding per written operation)"""
+    from pmctf_oracle import clib
+    f = np.float32
+    al, be = f(alpha), f(beta)
+    if op == ops.EW_COPY: return a.copy()
+    if op == ops.EW_ADD: return a + b
+    if op == ops.EW_SUB: return a - b
+    if op == ops.EW_MUL: return a * b
+    if op == ops.EW_DIV: return a / b
+    if op == ops.EW_MULS: return a * al
+    if op == ops.EW_DIVS: return a / al
+    if op == ops.EW_ADD_MULS: return a + b * al
+    if op == ops.EW_SUB_MULS: return a - b * al
+    if op == ops.EW_ADD_MULS_MULS: return (a + b * al) * be
+    if op == ops.EW_CLAMP_MULS: return np.clip(a * al, -be, be)
+    if op == ops.EW_ROUND_CLAMP_MULS: return np.rint(np.clip(a * al, -be, be))
+    if op == ops.EW_ROUND: return np.rint(a)
+    if op == ops.EW_LEAKY: return np.where(a > 0, a, a * al).astype(f)
+    if op == ops.EW_ADD_MULS2: return a + (b * al) * be
+    if op == ops.EW_SUB_MULS2: return a - (b * al) * be
+    if op == ops.EW_ROUND_CLAMP: return np.rint(np.clip(a, al, be))
+    if op == ops.EW_TANH: return clib.tanh(a)
+    raise AssertionError(op)
+
+
+def test_elementwise_ops_every_layout(cuda):
+    """pmctf_ew_f32 over the operand layouts the engine hands it — whole planes and whole NHWC tensors (the flat 16-byte
+    form, with and without a vector tail), channel slices of NHWC tensors, row / column windows, a broadcast second
+    operand, in place — every op against a numpy float32 restatement: bit-exact."""
+    from pMCTF.hip import ops
+    r = _rng(99)
+
+    def dev(x):
+        return torch.from_numpy(x).cuda()
+    layouts = []
+    for shape in [(1, 1, 37, 53), (1, 1, 64, 96), (2, 3, 20, 36)]:                 # planar, dense: flat scalar / flat vec
+        layouts.append(("planar", shape, lambda t: t, lambda t: t))
+    layouts.append(("nhwc dense", (2, 16, 20, 36), lambda t: t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), None))
+    layouts.append(("nhwc channel slice", (1, 8, 19, 23),
+                    lambda t: torch.cat([t, t], 1).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)[:, 8:], None))
+    layouts.append(("row window", (1, 2, 16, 40), lambda t: torch.cat([t, t, t], 2)[:, :, 16:32], None))
+    layouts.append(("column window", (2, 1, 18, 24), lambda t: torch.cat([t, t], 3)[:, :, :, 24:], None))
+    binary = {ops.EW_ADD, ops.EW_SUB, ops.EW_MUL, ops.EW_DIV, ops.EW_ADD_MULS, ops.EW_SUB_MULS, ops.EW_ADD_MULS_MULS,
+              ops.EW_ADD_MULS2, ops.EW_SUB_MULS2}
+    for name, shape, place, _ in layouts:
+        a = (r.standard_normal(shape, dtype=np.float32) * 3).astype(np.float32)
+        b = (r.standard_normal(shape, dtype=np.float32) + np.float32(2.5)).astype(np.float32)
+        ta, tb = place(dev(a)), place(dev(b))
+        assert tuple(ta.shape) == shape
+        for op in range(18):
+            alpha, beta = (0.37, 2.25) if op != ops.EW_ROUND_CLAMP else (-2.0, 3.0)
+            want = _ew_expected(op, a, b, alpha, beta, ops)
+            got = ops.ew(op, ta, tb if op in binary else None, alpha, beta)
+            assert_same(got.cpu().numpy(), want, f"ew op {op} on {name} {shape}")
+        # second operand broadcast over the planes (stride 0), and the result written over the first operand
+        b1 = b[:1, :1]
+        got = ops.ew(ops.EW_SUB_MULS, ta, dev(b1).expand(*shape), 0.37)
+        assert_same(got.cpu().numpy(), a - b1 * np.float32(0.37), f"ew broadcast on {name}")
+        tc = ta.clone() if ta.is_contiguous() else place(dev(a))
+        ops.ew(ops.EW_ADD, tc, tb, out=tc)
+        assert_same(tc.cpu().numpy(), a + b, f"ew in place on {name}")

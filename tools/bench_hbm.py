@@ -13,18 +13,29 @@ PEAK = 8000.0  # GB/s
 
 
 def timed(fn, reps=20):
+    """GPU time per launch: the repetitions are captured into one HIP graph and the replay is bracketed by events, so that
+    a launch of a few microseconds is not measured at the rate the host can enqueue it"""
     fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+ROWS = []      # (name, seconds per launch, algorithmic bytes): bench.py's `hbm_kernels` block reads these
+
+
 def report(name, nbytes, t):
+    ROWS.append((name, t, nbytes))
     print(f"{name:58s} {t * 1e6:8.1f} us  {nbytes / 1e6:8.1f} MB  {nbytes / t / 1e9:7.0f} GB/s  ({nbytes / t / 1e9 / PEAK * 100:4.1f} % of HBM peak)")
 
 
@@ -40,6 +51,9 @@ def main():
     y = torch.randn(1, 1, H, W, device=dev)
     flow = torch.randn(1, 2, H, W, device=dev) * 3
     lx, ly = torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev)
+    y2 = torch.empty_like(y)
+    report("reference point: copy of ONE 1152x1920 f32 plane (8 B/px; what a launch of this size can reach)", H * W * 8,
+           timed(lambda: y2.copy_(y)))
     report("flow_warp 1x1x1152x1920 (4 B in, 8 B flow, 4 B out /px)", H * W * 16, timed(lambda: ops.flow_warp(y, flow, lx, ly)))
     a, b = torch.randn(1, 1, H, W, device=dev), torch.randn(1, 1, H, W, device=dev)
     report("ew add 1x1x1152x1920 (12 B/elem)", H * W * 12, timed(lambda: ops.ew(ops.EW_ADD, a, b)))
@@ -60,9 +74,10 @@ def main():
            timed(lambda: ops.conv3x3_cin1_dual(c116, yin, ops.ACT_TANH)))
     x64 = torch.randn(1, 576, 960, 64, device=dev)
     report("nearest x2 upsampling 1x576x960x64 (20 B/input elem)", x64.numel() * 20, timed(lambda: ops.nearest_up2(x64)))
-    report("avg-pool 2x2 1x3x1152x1920 (5 B/input elem)", 3 * H * W * 5, timed(lambda: ops.avgpool2(torch.empty(0, device=dev) if False else y3)))
+    y3 = torch.randn(1, 3, H, W, device=dev)
+    report("avg-pool 2x2 1x3x1152x1920 (5 B/input elem)", 3 * H * W * 5, timed(lambda: ops.avgpool2(y3)))
+    return ROWS
 
 
 if __name__ == "__main__":
-    y3 = torch.randn(1, 3, 1152, 1920, device="cuda")
     main()
