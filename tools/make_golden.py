@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--sequence", default="pan", choices=["pan", "layers"],
                     help="synthetic sequence: pmctf_synth.synth_yuv420 (global pan) or synth_yuv420_layers (two motion "
                          "layers and an occluding square)")
+    ap.add_argument("--me_downsample", type=int, default=1, choices=[1, 2],
+                    help="motion estimated and coded at reduced resolution (the GOP loop of test_pMCTF_CA.py:code_one_gop)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -272,7 +274,8 @@ def main():
                 trace.clear()
 
             trace.clear()
-            enc = pmctf_gop.encode_gop(net, frames, H, W, q_index=args.q_index, bin_folder=td, on_pair=on_pair)
+            enc = pmctf_gop.encode_gop(net, frames, H, W, q_index=args.q_index, bin_folder=td, on_pair=on_pair,
+                                       me_downsample=args.me_downsample)
             rec_frames = pmctf_gop.decode_gop(net, enc["frames_coded"])
             ps = pmctf_gop.gop_psnr(rec_frames, frames, H, W)
             out["gop.bits"] = np.array(enc["bits"], np.float64)
@@ -344,6 +347,8 @@ def main():
         suffix += f"_q{args.q_index}"
     if args.sequence != "pan":
         suffix += "_" + args.sequence
+    if args.me_downsample != 1:
+        suffix += f"_ds{args.me_downsample}"
     path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}{suffix}.meta.json"), "w"), indent=1)
