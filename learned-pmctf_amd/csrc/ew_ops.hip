@@ -59,6 +59,30 @@ __global__ void ew_kernel(int op, float *out, View vo, const float *a, View va, 
     }
 }
 
+// Channel-fastest views whose channel count and strides are multiples of four (channel slices / concatenations of NHWC
+// tensors, the parity-class gathers of the four-step coder): four channels per thread, 16-byte accesses, one index split
+// per four elements.  Same ew_apply per element.
+template <typename IT>
+__global__ void ew_c4_kernel(int op, float *out, View vo, const float *a, View va, const float *b, View vb, int N, int C4,
+                             int H, int W, float alpha, float beta) {
+    const long total = (long)N * C4 * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        IT r = (IT)idx;
+        const int c = (int)(r % C4) * 4; r /= C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        const float4 av = *(const float4 *)(a + n * va.s[0] + c + h * va.s[2] + w * va.s[3]);
+        const float4 bv = b ? *(const float4 *)(b + n * vb.s[0] + c + h * vb.s[2] + w * vb.s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o;
+        o.x = ew_apply(op, av.x, bv.x, alpha, beta);
+        o.y = ew_apply(op, av.y, bv.y, alpha, beta);
+        o.z = ew_apply(op, av.z, bv.z, alpha, beta);
+        o.w = ew_apply(op, av.w, bv.w, alpha, beta);
+        *(float4 *)(out + n * vo.s[0] + c + h * vo.s[2] + w * vo.s[3]) = o;
+    }
+}
+
 // All operands dense with the same strides (whole planes, whole NHWC / NCHW tensors): the op is a flat map over `total`
 // consecutive floats, whatever the logical order — no index arithmetic, 16-byte accesses.  Same ew_apply per element.
 template <bool VEC>
@@ -380,6 +404,19 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
         }
     }
     const bool small = total < (1L << 31);
+    if (cfast && (C & 3) == 0 && vo.s[1] == 1 && va.s[1] == 1 && (!b || (sb && vb.s[1] == 1)) &&
+        (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        bool ok4 = true;        // every other stride a multiple of four elements: all 16-byte accesses are aligned
+        const int dims[4] = {N, C, H, W};
+        for (int i = 0; i < 4; ++i)
+            if (i != 1 && dims[i] != 1 && (((vo.s[i] | va.s[i]) & 3) != 0 || (b && (vb.s[i] & 3) != 0))) ok4 = false;
+        if (ok4) {
+            const unsigned g = grid_for(total >> 2);
+            if (small) PM_LAUNCH((ew_c4_kernel<int>), dim3(g), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C / 4, H, W, alpha, beta);
+            else PM_LAUNCH((ew_c4_kernel<long>), dim3(g), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C / 4, H, W, alpha, beta);
+            return launch_ok();
+        }
+    }
     if (cfast) {
         if (small) PM_LAUNCH((ew_kernel<true, int>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
         else PM_LAUNCH((ew_kernel<true, long>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);

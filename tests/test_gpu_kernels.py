@@ -388,6 +388,11 @@ def test_elementwise_ops_every_layout(cuda):
     layouts.append(("nhwc dense", (2, 16, 20, 36), lambda t: t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), None))
     layouts.append(("nhwc channel slice", (1, 8, 19, 23),
                     lambda t: torch.cat([t, t], 1).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)[:, 8:], None))
+    layouts.append(("nhwc parity-class gather", (1, 12, 9, 11),          # as_nchw(t)[:, :, 1::2, 0::2] of a (1,18,22,12) tensor
+                    lambda t: torch.nn.functional.interpolate(t, scale_factor=2, mode="nearest")
+                    .permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)[:, :, 1::2, 0::2], None))
+    layouts.append(("nhwc odd channel slice", (1, 8, 10, 14),            # 8 of 16 channels from channel 3 on: not 16-byte aligned
+                    lambda t: torch.cat([t[:, :3], t, t[:, :5]], 1).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)[:, 3:11], None))
     layouts.append(("row window", (1, 2, 16, 40), lambda t: torch.cat([t, t, t], 2)[:, :, 16:32], None))
     layouts.append(("column window", (2, 1, 18, 24), lambda t: torch.cat([t, t], 3)[:, :, :, 24:], None))
     binary = {ops.EW_ADD, ops.EW_SUB, ops.EW_MUL, ops.EW_DIV, ops.EW_ADD_MULS, ops.EW_SUB_MULS, ops.EW_ADD_MULS_MULS,
