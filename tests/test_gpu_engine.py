@@ -472,10 +472,11 @@ def test_gop4_960x544_vs_reference(setup):
     assert same >= 9 and diff <= 2, (same, diff)
 
 
-def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080)):
+def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_%dx%d_gop%d_me4%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
-                                                                      "" if sequence == "pan" else "_" + sequence))
+                        "reference_%dx%d_gop%d_me4%s%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
+                                                                        "" if sequence == "pan" else "_" + sequence,
+                                                                        "" if me_downsample == 1 else f"_ds{me_downsample}"))
 
 
 # BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
@@ -490,13 +491,13 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080)):
+def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1):
     import hashlib
     import pmctf_gop
-    key = (gop, q_index, sequence, size)
+    key = (gop, q_index, sequence, size, me_downsample)
     if key in _headline_cache:
         return _headline_cache[key]
-    g = np.load(_digest_path(gop, q_index, sequence, size))
+    g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample))
     net, _ = product_model(4)
     net.engine().keep_streams = True
     w, h = size
@@ -506,7 +507,7 @@ def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080)):
         import pmctf_synth
         fr = [list(pmctf_synth.frames_to_tensors(f, device="cuda")) for f in pmctf_synth.synth_yuv420_layers(w, h, gop)]
     with tempfile.TemporaryDirectory() as td:
-        enc = pmctf_gop.encode_gop(net, fr, h, w, q_index, td)
+        enc = pmctf_gop.encode_gop(net, fr, h, w, q_index, td, me_downsample=me_downsample)
         rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
         ps = pmctf_gop.gop_psnr(rec, fr, h, w)
     same = diff = 0
@@ -636,6 +637,19 @@ def test_2160p_pair_vs_reference(cuda):
     --me_stages 4 --sequence layers): bits identical, PSNR within 1e-4 dB."""
     r = _headline_run(2, 3, "layers", (3840, 2160))
     assert r["same"] + r["diff"] == 5
+    assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
+    assert r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+    assert r["lengths_equal"]
+
+
+def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
+    """The content-adaptive script's GOP schedule at full size: 1920x1080, GOP 8, q_index 3, motion estimated and coded
+    at HALF resolution (me_downsample=2, test_pMCTF_CA.py:code_one_gop) against the digest of the real reference's CPU run
+    (tools/make_golden.py --gop_only --width 1920 --height 1080 --gop 8 --me_stages 4 --me_downsample 2): bits of every
+    frame identical, PSNR within 1e-4 dB."""
+    r = _headline_run(8, 3, me_downsample=2)
+    assert r["same"] + r["diff"] == 3 * 7 + 2
     assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
     assert r["bits_mv"] == r["ref_bits_mv"]
     assert r["psnr_err"] < 1e-4
