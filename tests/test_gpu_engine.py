@@ -643,6 +643,30 @@ def test_2160p_pair_vs_reference(cuda):
     assert r["lengths_equal"]
 
 
+@pytest.mark.xfail(strict=True, reason="measured: frames 0 and 4 are one 32-bit rANS word longer than the reference's "
+                                       "(bit deltas [32, 0, 0, 0, 32, 0, 0, 0] of 4.97 / 4.20 Mbit; frame 4's in its motion stream), max PSNR error 3.4e-5 dB "
+                                       "(last-bit rounding of conv sums, PM-F32 vs ATen; pinned exactly by the test below)")
+def test_1366x768_gop8_vs_reference(cuda):
+    """A frame size that is a multiple of nothing the path tiles by (1366x768 -> padded to 1408x768; chroma 683x384): GOP 8,
+    q_index 3, four ME stages against the digest of the real reference's CPU run (tools/make_golden.py --gop_only --width
+    1366 --height 768 --gop 8 --me_stages 4): bits of every frame identical, PSNR within 1e-4 dB."""
+    r = _headline_run(8, 3, size=(1366, 768))
+    assert r["same"] + r["diff"] == 3 * 7 + 2
+    assert r["bits"] == r["ref_bits"], f"bits per frame differ from the reference: {r['dbits']}"
+    assert r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+    assert r["lengths_equal"]
+
+
+def test_1366x768_gop8_pinned_deviation(cuda):
+    """What the strict test above measured, pinned exactly: any drift (better or worse) fails."""
+    r = _headline_run(8, 3, size=(1366, 768))
+    assert r["dbits"] == [32, 0, 0, 0, 32, 0, 0, 0]
+    # frame 4's extra word is in its motion stream, frame 0's in the L subband stream
+    assert [int(a - b) for a, b in zip(r["bits_mv"], r["ref_bits_mv"])] == [0, 0, 0, 0, 32, 0, 0, 0]
+    assert r["psnr_err"] < 1e-4 and r["same"] == 16 and r["diff"] == 7
+
+
 def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
     """The content-adaptive script's GOP schedule at full size: 1920x1080, GOP 8, q_index 3, motion estimated and coded
     at HALF resolution (me_downsample=2, test_pMCTF_CA.py:code_one_gop) against the digest of the real reference's CPU run
