@@ -57,6 +57,15 @@ def main():
     report("flow_warp 1x1x1152x1920 (4 B in, 8 B flow, 4 B out /px)", H * W * 16, timed(lambda: ops.flow_warp(y, flow, lx, ly)))
     a, b = torch.randn(1, 1, H, W, device=dev), torch.randn(1, 1, H, W, device=dev)
     report("ew add 1x1x1152x1920 (12 B/elem)", H * W * 12, timed(lambda: ops.ew(ops.EW_ADD, a, b)))
+    report("even-row split of a 1152x1920 plane (strided view -> dense, 8 B/output elem)", H // 2 * W * 8,
+           timed(lambda: ops.ew(ops.EW_COPY, a[:, :, ::2, :])))
+    half = torch.randn(1, 1, H // 2, W, device=dev)
+    report("transpose of a 576x1920 plane (8 B/elem)", H // 2 * W * 8,
+           timed(lambda: ops.ew(ops.EW_COPY, half.permute(0, 1, 3, 2))))
+    t112 = torch.randn(1, 576, 960, 112, device=dev)
+    report("parity-class gather of a 1x576x960x112 tensor (8 B/output elem)", 288 * 480 * 112 * 8,
+           timed(lambda: ops.ew(ops.EW_COPY, ops.as_nchw(t112)[:, :, 1::2, 0::2], out=ops.as_nchw(ops.empty_nhwc(1, 288, 480, 112, dev)))))
+    del t112
     x112 = torch.randn(1, 576, 960, 112, device=dev)
     dw = ops.DepthwiseConv2d(torch.randn(112, 1, 3, 3), torch.randn(112))
     report("depthwise 3x3 1x576x960x112 (8 B/elem)", x112.numel() * 8, timed(lambda: dw(x112)))
