@@ -83,6 +83,31 @@ __global__ void ew_c4_kernel(int op, float *out, View vo, const float *a, View v
     }
 }
 
+// Unary op whose input is the TRANSPOSE of a dense plane (element (h, w) at w*H + h) written to dense rows: 32x32 tiles
+// through LDS, so that both the reads (along h) and the writes (along w) are coalesced.  The strided-view form reads
+// 64 different cache lines per wave (8.8 us for a 576x1920 plane against 3.8 us for a copy of the same bytes).
+__global__ __launch_bounds__(256) void ew_transpose_kernel(int op, float *out, const float *a, int C, int H, int W,
+                                                           long so_n, long so_c, long sa_n, long sa_c, float alpha,
+                                                           float beta) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const int n = blockIdx.z / C, c = blockIdx.z - n * C;
+    const float *src = a + n * sa_n + c * sa_c;
+    float *dst = out + n * so_n + c * so_c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = w0 + ty + 8 * j, h = h0 + tx;
+        if (w < W && h < H) tile[ty + 8 * j][tx] = src[(long)w * H + h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int h = h0 + ty + 8 * j, w = w0 + tx;
+        if (h < H && w < W) dst[(long)h * W + w] = ew_apply(op, tile[tx][ty + 8 * j], 0.0f, alpha, beta);
+    }
+}
+
 // All operands dense with the same strides (whole planes, whole NHWC / NCHW tensors): the op is a flat map over `total`
 // consecutive floats, whatever the logical order — no index arithmetic, 16-byte accesses.  Same ew_apply per element.
 template <bool VEC>
@@ -402,6 +427,12 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
                 PM_LAUNCH(ew_flat_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, op, out, a, b, total, alpha, beta);
             return launch_ok();
         }
+    }
+    if (!b && H > 1 && W > 1 && vo.s[3] == 1 && vo.s[2] == W && va.s[2] == 1 && va.s[3] == H && (long)N * C < 65536 &&
+        (N == 1 || (vo.s[0] >= (long)H * W && va.s[0] >= (long)H * W)) && (C == 1 || (vo.s[1] >= (long)H * W && va.s[1] >= (long)H * W))) {
+        const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 31) / 32), (unsigned)(N * C));
+        PM_LAUNCH(ew_transpose_kernel, grid, dim3(256), 0, st, op, out, a, C, H, W, vo.s[0], vo.s[1], va.s[0], va.s[1], alpha, beta);
+        return launch_ok();
     }
     const bool small = total < (1L << 31);
     if (cfast && (C & 3) == 0 && vo.s[1] == 1 && va.s[1] == 1 && (!b || (sb && vb.s[1] == 1)) &&
