@@ -1404,7 +1404,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"C16_OCC", 2, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"C16_OCC", 2, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}, {"BIGPX_NOSPLIT", 200000, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1634,7 +1634,9 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     //     that fill whole rounds of 512 go to it, the remaining rows (a partial round) are cut 4x finer (4x16 tiles)
     //     so the tail of the launch costs a quarter of a round instead of a full one.
     const bool split = knob("SPLIT") != 0;
-    const long big_px = split ? knob("BIGPX") : 400000;
+    // without the cut (launch plans: another stream fills the tail of a launch) the 8x32-tile kernel pays from 200 000
+    // pixels on (2x288x480), measured on the harness loop; 1x288x480 (1.05 rounds of 512 workgroups) stays on 4x16 tiles
+    const long big_px = split ? knob("BIGPX") : knob("BIGPX_NOSPLIT");
     if (MTP < 8 && a.S == 1 && a.KH <= 7 && px >= big_px) {
         if (split && MTP >= 7 && wave_eligible(a)) {
             // a CU works through its workgroups two at a time: the launch ends when the CU with the most workgroups

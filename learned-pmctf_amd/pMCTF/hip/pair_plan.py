@@ -96,8 +96,16 @@ class PairPlan:
         # dispatcher; nothing else launches while a plan is recorded, see HipEngine.gate)
         from . import lib as _lib
         L = _lib.hip()
-        split_knob = L.pmctf_conv2d_get_option(b"SPLIT")
-        L.pmctf_conv2d_set_option(b"SPLIT", int(os.environ.get("PMCTF_PLAN_SPLIT", "0")))
+        # Measured on the harness loop (tools/eager_gop.py, same box, CONV_OPTIONS): with the cut off, planes of 200 000 to
+        # 400 000 pixels (chroma's level-0 subbands, 2x288x480) are better on the barrier-free 8x32-tile kernel than on the
+        # 4x16-tile one (BIGPX_NOSPLIT, the dispatcher's default: 5.62 -> 5.67 frames/s), and splitting a launch by cout
+        # tile only pays below 40 000 pixels instead of 70 000 (5.66 -> 5.68): the other stream supplies the workgroups a
+        # lone launch lacks.
+        plan_knobs = {b"SPLIT": int(os.environ.get("PMCTF_PLAN_SPLIT", "0")),
+                      b"MSPLIT_PX": int(os.environ.get("PMCTF_PLAN_MSPLIT_PX", "40000"))}
+        saved_knobs = {k: L.pmctf_conv2d_get_option(k) for k in plan_knobs}
+        for k, v in plan_knobs.items():
+            L.pmctf_conv2d_set_option(k, v)
         # No finaliser may run while a capture is open: the launch plans of a model that has been dropped are destroyed
         # when the cyclic collector finds them (an engine outlives its model as unreachable garbage), and destroying HIP
         # graphs / returning their pools inside another capture ends the process.  Collect them NOW, keep the collector
@@ -112,7 +120,8 @@ class PairPlan:
         finally:
             if gc_was_on:
                 gc.enable()
-            L.pmctf_conv2d_set_option(b"SPLIT", split_knob)
+            for k, v in saved_knobs.items():
+                L.pmctf_conv2d_set_option(k, v)
 
     def _record(self, eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample):
         cap = _Capture(pool_y)

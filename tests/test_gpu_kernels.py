@@ -226,8 +226,9 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     xd = nhwc(x)
     L = lib.hip()
     defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1,
-                "C16": 1, "C16_WGS": 512, "C16_OCC": 2, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1, "K33_SMALL": 1}
-    settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0}, {"BIGPX": 0, "MSPLIT_PX": 0},
+                "C16": 1, "C16_WGS": 512, "C16_OCC": 2, "NBUF1": 1, "K33": 1, "WAVE_SMALL": 1, "K11": 1, "K77": 1, "K33_SMALL": 1, "BIGPX_NOSPLIT": 200000}
+    settings = [{}, {"MSPLIT_PX": 0}, {"MSPLIT_PX": 1 << 40}, {"SPLIT": 0, "MSPLIT_PX": 0},
+                {"SPLIT": 0, "MSPLIT_PX": 0, "BIGPX_NOSPLIT": 0}, {"SPLIT": 0, "MSPLIT_PX": 0, "BIGPX_NOSPLIT": 1 << 40}, {"BIGPX": 0, "MSPLIT_PX": 0},
                 {"NT": 1, "MSPLIT_PX": 0}, {"NT": 2, "MSPLIT_PX": 0}, {"NT": 4, "MSPLIT_PX": 0},
                 {"NT": 4, "MSPLIT_PX": 0, "WAVE": 0}, {"V1": 1, "MSPLIT_PX": 0}, {"V2": 1, "MSPLIT_PX": 0},
                 {"V2": 1, "MSPLIT_PX": 1 << 40}, {"RES": 1, "MSPLIT_PX": 1 << 40}, {"RES": 2, "MSPLIT_PX": 1 << 40}, {"MSPLIT_NT": 2, "MSPLIT_PX": 1 << 40},
