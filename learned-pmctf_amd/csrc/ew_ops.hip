@@ -448,6 +448,22 @@ extern "C" int pmctf_ew_f32(int op, float *out, const int64_t *so, const float *
             return launch_ok();
         }
     }
+    if (!cfast && (W & 3) == 0 && vo.s[3] == 1 && va.s[3] == 1 && (!b || (sb && vb.s[3] == 1)) &&
+        (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        // planar views whose rows are contiguous (even / odd row splits and interleaves of the lifting, row windows): the
+        // four-per-thread kernel with the row in the role of the channel vector
+        const int dims[4] = {N, C, H, W};
+        bool ok4 = true;
+        for (int i = 0; i < 3; ++i)
+            if (dims[i] != 1 && (((vo.s[i] | va.s[i]) & 3) != 0 || (b && (vb.s[i] & 3) != 0))) ok4 = false;
+        if (ok4) {
+            auto rows = [](const View &v) { View r; r.s[0] = v.s[0]; r.s[1] = 1; r.s[2] = v.s[1]; r.s[3] = v.s[2]; return r; };
+            const unsigned g = grid_for(total >> 2);
+            if (small) PM_LAUNCH((ew_c4_kernel<int>), dim3(g), dim3(256), 0, st, op, out, rows(vo), a, rows(va), b, rows(vb), N, W / 4, C, H, alpha, beta);
+            else PM_LAUNCH((ew_c4_kernel<long>), dim3(g), dim3(256), 0, st, op, out, rows(vo), a, rows(va), b, rows(vb), N, W / 4, C, H, alpha, beta);
+            return launch_ok();
+        }
+    }
     if (cfast) {
         if (small) PM_LAUNCH((ew_kernel<true, int>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);
         else PM_LAUNCH((ew_kernel<true, long>), dim3(grid_for(total)), dim3(256), 0, st, op, out, vo, a, va, b, vb, N, C, H, W, alpha, beta);

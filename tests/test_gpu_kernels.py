@@ -395,6 +395,8 @@ def test_elementwise_ops_every_layout(cuda):
     layouts.append(("nhwc odd channel slice", (1, 8, 10, 14),            # 8 of 16 channels from channel 3 on: not 16-byte aligned
                     lambda t: torch.cat([t[:, :3], t, t[:, :5]], 1).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)[:, 3:11], None))
     layouts.append(("transposed planes", (2, 3, 37, 70), lambda t: t.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), None))
+    layouts.append(("even rows", (1, 2, 9, 20), lambda t: torch.repeat_interleave(t, 2, dim=2)[:, :, ::2, :], None))
+    layouts.append(("odd rows, ragged width", (2, 1, 7, 18), lambda t: torch.repeat_interleave(t, 2, dim=2)[:, :, 1::2, :], None))
     layouts.append(("row window", (1, 2, 16, 40), lambda t: torch.cat([t, t, t], 2)[:, :, 16:32], None))
     layouts.append(("column window", (2, 1, 18, 24), lambda t: torch.cat([t, t], 3)[:, :, :, 24:], None))
     binary = {ops.EW_ADD, ops.EW_SUB, ops.EW_MUL, ops.EW_DIV, ops.EW_ADD_MULS, ops.EW_SUB_MULS, ops.EW_ADD_MULS_MULS,
