@@ -212,3 +212,86 @@ def gop_psnr(frames_rec, frames_orig, pic_height, pic_width):
         pcr = psnr(rc[1:2], oc[1:2])
         out.append({"y": py, "cb": pcb, "cr": pcr, "yuv": (6.0 * py + pcb + pcr) / 8.0})
     return out
+
+
+def write_yuv(path, frames_u8):
+    """[(Y, Cb, Cr) uint8 arrays] -> planar 8-bit 4:2:0 file, the layout YUVReader / image_import read"""
+    with open(path, "wb") as f:
+        for planes in frames_u8:
+            for p in planes:
+                f.write(p.tobytes(order="C"))
+
+
+def read_gop(reader, gop, device, psize=128):
+    """GOP pictures from a YUVReader as the model's inputs: ([Y (1,1,Hp,Wp), UV (2,1,Hp/2,Wp/2)] zero padded right/bottom
+    to multiples of psize (chroma psize/2), the un-padded originals, (height, width)).  What the harness does per pair
+    at stage 0 (test_pMCTF_flex.py:151-192), done here per GOP."""
+    import torch.nn.functional as F
+    from pMCTF.utils.stream_helper import get_padding_size
+    padded, orig, size = [], [], None
+    for _ in range(gop):
+        y, cb, cr = (torch.from_numpy(p).float() for p in reader.read_one_frame())
+        assert size in (None, tuple(y.shape)), "picture size changes inside the sequence"
+        size = tuple(y.shape)
+        luma = y[None, None].to(device)
+        chroma = torch.stack((cb, cr))[:, None].to(device)
+        left, right, top, bottom = get_padding_size(size[0], size[1], p=psize)
+        orig.append([luma, chroma])
+        padded.append([F.pad(luma, (left, right, top, bottom)),
+                       F.pad(chroma, (left // 2, right // 2, top // 2, bottom // 2))])
+    return padded, orig, size
+
+
+def rgb_psnr(rec_y, rec_c, y, c):
+    """PSNR of the rounded RGB pictures (chroma bilinearly up-sampled), test_pMCTF_flex.py:312-321"""
+    from pMCTF.utils.util import ycbcr2rgb, yuv_420_to_444
+    to_rgb = lambda luma, chroma: torch.round(ycbcr2rgb(yuv_420_to_444((luma, chroma[0:1], chroma[1:2]))))
+    return psnr(to_rgb(y, c), to_rgb(rec_y, rec_c))
+
+
+def encode_sequence(codec, yuv_path, width, height, frame_num, gop, q_index, bin_folder, device,
+                    skip_decoding=True, psize=128):
+    """What the evaluation harness produces for one sequence (test_pMCTF_flex.py:run_test, 86-346) built from this
+    module's own pieces: pictures come from a planar .yuv through YUVReader and get_padding_size, every closed GOP goes
+    through encode_gop (one encode_one_stage call per pair, both per-pair report lines), decode_gop and gop_psnr, and
+    the per-frame tables are folded into the harness's log record by generate_log_json / dump_json.  MS-SSIM is
+    reported as 0 (pytorch_msssim is a third-party package the harness imports; not part of the path).
+    Returns {"log": record, "json": its text, "bits", "bpp_mv", "psnr", "psnr_rgb", "frame_types", "lines"}."""
+    import io
+    import time
+    from pMCTF.utils.video_eval_utils import dump_json, generate_log_json
+    from pMCTF.utils.yuv_reader import YUVReader
+    assert frame_num % gop == 0
+    reader = YUVReader(yuv_path, width, height, start_index=0)
+    tables = {k: [] for k in ("bits", "bpp_mv", "psnr", "psnr_rgb", "frame_types")}
+    lines = []
+    pairs = 0
+    seconds = {"encoding_time": 0.0, "decoding_time": 0.0}
+    t0 = time.time()
+    with torch.no_grad():
+        for _ in range(frame_num // gop):
+            padded, orig, (h, w) = read_gop(reader, gop, device, psize)
+            enc = encode_gop(codec, padded, h, w, q_index, bin_folder, skip_decoding=skip_decoding, psize=psize)
+            for r in enc["results"]:
+                pairs += 1
+                for k in seconds:
+                    seconds[k] += r[k]
+            lines += enc["log"]
+            rec = decode_gop(codec, enc["frames_coded"])
+            quality = gop_psnr(rec, orig, h, w)
+            tables["bits"] += enc["bits"]
+            tables["bpp_mv"] += [b / (h * w) for b in enc["bits_mv"]]
+            tables["psnr"] += [p["yuv"] for p in quality]
+            tables["frame_types"] += [0] + [1] * (gop - 1)          # the one coded L picture of a GOP, then its H pictures
+            for (ry, rc, _), (y, c) in zip(rec, orig):
+                crop_y = torch.round(ry.clamp(0, 255.0))[:, :, :h, :w]
+                crop_c = torch.round(rc.clamp(0, 255.0))[:, :, :h // 2, :w // 2]
+                tables["psnr_rgb"].append(rgb_psnr(crop_y, crop_c, y, c))
+    reader.close()
+    for k, label in (("encoding_time", "encoding"), ("decoding_time", "decoding")):
+        lines.append(f"{label} {pairs} P frames, average {seconds[k] / pairs * 1000:.0f} ms.")
+    record = generate_log_json(frame_num, tables["frame_types"], tables["bits"], tables["bpp_mv"], tables["psnr"],
+                               tables["psnr_rgb"], [0] * frame_num, height * width, time.time() - t0)
+    text = io.StringIO()
+    dump_json(record, text, float_digits=6, indent=2)
+    return dict(tables, log=record, json=text.getvalue(), lines=lines)

@@ -729,32 +729,38 @@ def test_batched_stage_equals_pair_by_pair(cuda):
                 np.array_equal(rb["traces"][k][1], rr["traces"][k][1]), k
 
 
-def test_literal_harness_loop_1080p_vs_reference(cuda):
-    """The reference's evaluation loop itself (tests/harness_loop.py: run_test of test_pMCTF_flex.py restated statement
-    for statement — YUVReader, padding, the .to(device) calls, the isinstance checks, BOTH per-pair f-strings,
-    np.mean per stage, generate_log_json, dump_json) on the headline configuration, the product in its DEFAULT mode:
-    1920x1080, GOP 16, q_index 3, four ME stages, write_stream + skip_decoding.  Bits of every frame identical to the real
-    reference's CPU run, PSNR within 1e-4 dB, the log is plain JSON; every call was coded when it returned (no
-    encode_stage_pairs batch, results are torch.Tensors and Python floats) and from the second GOP on every pair
-    replays a captured launch plan."""
+def test_sequence_driver_1080p_vs_reference(cuda):
+    """What the unmodified evaluation script relies on, asserted as a CONTRACT on the headline configuration (1920x1080,
+    GOP 16, q_index 3, four ME stages, write_stream + skip_decoding), the product in its DEFAULT mode, driven by
+    pmctf_gop.encode_sequence (.yuv file -> YUVReader -> padding -> one encode_one_stage call per pair, the two per-pair
+    report lines formatted before the next call -> synthesis -> PSNR -> log record):
+      * every call returns the reference's result keys, tensors as torch.Tensor, bit counts / times as Python floats,
+        the five (three) files of the pair on disk with their sizes behind the bit counts;
+      * nothing was deferred or batched (no encode_stage_pairs), from the second GOP on every pair replays a plan;
+      * bits of every frame identical to the real reference's CPU run, PSNR within 1e-4 dB;
+      * the log record has the script's keys and is plain JSON."""
     import json
+    import pmctf_gop
     import pmctf_synth
-    from harness_loop import run_sequence, write_yuv
     from pMCTF.hip import pair_plan
-    g = np.load(_digest_path(16, 3))
-    import pmctf_synth as ps_
     from pMCTF.models.video.pMCTF_L import pMCTF
-    net = pMCTF(num_me_stages=4).eval()                     # exactly what encode_one() of the script builds
-    net.load_state_dict(ps_.synth_state_dict(net.state_dict(), seed=0), strict=True)
-    net = net.to("cuda")
-    net.eval()
+    g = np.load(_digest_path(16, 3))
+    net = pMCTF(num_me_stages=4).eval()                     # what the script builds: ctor, strict load, .to, update
+    net.load_state_dict(pmctf_synth.synth_state_dict(net.state_dict(), seed=0), strict=True)
+    net = net.to("cuda").eval()
     net.update(force=True)
     w, h, gop = 1920, 1080, 16
     seen, batches, runs = [], [], []
     orig_one, orig_stage, orig_run = net.encode_one_stage, net.encode_stage_pairs, pair_plan.PairPlan.run
+    keys = {"L_t", "H_t", "L_tc", "H_tc", "bit_H", "bit_L", "bit_Lc", "bit_Hc", "bit_ME", "mv_hat", "dpb",
+            "decoding_time", "encoding_time"}
 
     def spy(**kw):
         r = orig_one(**kw)
+        out = kw["output_path"]
+        files = [out, out.replace(".bin", "_mv.bin"), out.replace(".bin", "_C_main.bin")]
+        assert all(os.path.getsize(f) > 0 for f in files), "a pair's files exist when its call returns"
+        assert r["bit_H"] + r["bit_ME"] == 8.0 * sum(os.path.getsize(f) for f in files)
         seen.append(r)
         return r
     net.encode_one_stage = spy
@@ -764,27 +770,31 @@ def test_literal_harness_loop_1080p_vs_reference(cuda):
         with tempfile.TemporaryDirectory() as td:
             yuv = os.path.join(td, "Synth_1920x1080_120fps_420_8bit_YUV.yuv")
             fr8 = pmctf_synth.synth_yuv420(w, h, gop)
-            write_yuv(yuv, fr8 + fr8)                       # two GOPs of the same frames: the second one only replays
+            pmctf_gop.write_yuv(yuv, fr8 + fr8)             # two GOPs of the same frames: the second one only replays
             bins = os.path.join(td, "bin")
             os.makedirs(bins)
-            log, bits, psnrs, printed, text = run_sequence(net, yuv, w, h, 2 * gop, gop, 3, bins, "cuda")
+            out = pmctf_gop.encode_sequence(net, yuv, w, h, 2 * gop, gop, 3, bins, "cuda")
             assert len(os.listdir(bins)) == 3 * (gop - 1) + 2
     finally:
         pair_plan.PairPlan.run = orig_run
     assert batches == [] and len(seen) == 2 * (gop - 1)
     assert len(runs) == (gop - 1) - 7 + (gop - 1)           # first GOP: 7 configurations recorded, the rest replayed
     for r in seen:                                          # finished values, call by call
+        assert keys <= set(r)
         assert all(type(r[k]) is torch.Tensor for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"))
         assert all(type(r[k]) is float for k in ("bit_H", "bit_Hc", "bit_ME", "encoding_time"))
         assert all(type(v) is torch.Tensor for v in r["dpb"].values())
     ref_bits = g["gop.bits"].tolist()
+    bits, psnrs = out["bits"], out["psnr"]
     assert bits[:gop] == ref_bits and bits[gop:] == ref_bits
     assert np.abs(np.array(psnrs[:gop]) - g["gop.psnr_yuv"]).max() < 1e-4
     assert psnrs[gop:] == psnrs[:gop]
-    parsed = json.loads(text)
+    parsed = json.loads(out["json"])
+    assert {"i_frame_num", "p_frame_num", "ave_all_frame_bpp", "ave_all_frame_psnr", "frame_bpp", "frame_psnr",
+            "frame_type", "test_time"} <= set(parsed)
     assert parsed["i_frame_num"] == 2 and parsed["p_frame_num"] == 2 * (gop - 1)
     assert abs(parsed["ave_all_frame_bpp"] - float(g["gop.bits"].sum()) / (gop * w * h)) < 1e-6
-    assert sum(l.startswith("percentage MV") for l in printed) == 2 * (gop - 1)
+    assert sum(l.startswith("percentage MV") for l in out["lines"]) == 2 * (gop - 1)
 
 
 def test_pair_plan_equals_stream_launches(cuda):

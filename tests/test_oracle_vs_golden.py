@@ -74,28 +74,40 @@ def test_gop4_bits_and_psnr_torch_backend(sd):
             assert r["files"][name] == g[f"gop.pair{i}.file.{key}"].tobytes()
 
 
-def test_harness_loop_restatement_reproduces_the_reference_run(sd):
-    """tests/harness_loop.py (run_test of test_pMCTF_flex.py restated: .yuv reader, padding, per-pair prints, log JSON) with
-    the oracle as the codec reproduces what the REAL script's loop produced for the golden GOP-4: per-frame bits and
-    PSNR — so the GPU test that drives the product through the same helper compares like with like."""
+def test_sequence_driver_reproduces_the_reference_run(sd):
+    """pmctf_gop.encode_sequence (the build's own driver of a whole sequence: .yuv reader, padding, one encode_one_stage
+    call per pair with both report lines, synthesis, PSNR, log record) with the oracle as the codec reproduces what the
+    REAL script's loop produced for the golden GOP-4: per-frame bits, motion bits and PSNR — so the GPU test that drives
+    the product through the same function compares like with like.  The contract the script relies on is asserted on
+    the way: per-frame tables of plain numbers, one L picture per GOP, the record's keys, JSON text."""
     import json
     import os
+    import pmctf_gop
     import pmctf_synth
-    from harness_loop import run_sequence, write_yuv
     from pmctf_oracle.model import Oracle
     g = golden()
     o = Oracle(sd, 1, "torch")
     with tempfile.TemporaryDirectory() as td:
         yuv = os.path.join(td, "seq.yuv")
-        write_yuv(yuv, pmctf_synth.synth_yuv420(W, H, 4))
+        pmctf_gop.write_yuv(yuv, pmctf_synth.synth_yuv420(W, H, 4))
+        assert os.path.getsize(yuv) == 4 * W * H * 3 // 2
         bins = os.path.join(td, "bin")
         os.makedirs(bins)
-        log, bits, psnrs, printed, text = run_sequence(o, yuv, W, H, 4, 4, 3, bins, "cpu")
-    assert bits == g["gop.bits"].tolist()
-    assert np.abs(np.array(psnrs) - g["gop.psnr_yuv"]).max() < 1e-4
-    parsed = json.loads(text)
+        out = pmctf_gop.encode_sequence(o, yuv, W, H, 4, 4, 3, bins, "cpu")
+        assert sorted(os.listdir(bins)) == sorted(["0_main.bin", "0_C_main.bin"] + [f"{k}{s}" for k in (1, 2, 3)
+                                                  for s in (".bin", "_mv.bin", "_C_main.bin")])
+    assert out["bits"] == g["gop.bits"].tolist()
+    assert np.allclose(np.array(out["bpp_mv"]) * (W * H), g["gop.bits_mv"], rtol=0, atol=1e-9)
+    assert np.abs(np.array(out["psnr"]) - g["gop.psnr_yuv"]).max() < 1e-4
+    assert out["frame_types"] == [0, 1, 1, 1]
+    assert all(type(v) is float for k in ("bits", "bpp_mv", "psnr", "psnr_rgb") for v in out[k])
+    parsed = json.loads(out["json"])
+    assert {"frame_pixel_num", "i_frame_num", "p_frame_num", "ave_i_frame_bpp", "ave_p_frame_bpp", "ave_all_frame_bpp",
+            "ave_all_frame_psnr", "frame_bpp", "frame_psnr", "frame_type", "test_time"} <= set(parsed)
+    assert parsed["i_frame_num"] == 1 and parsed["p_frame_num"] == 3
     assert abs(parsed["ave_all_frame_bpp"] - float(g["gop.bits"].sum()) / (4 * W * H)) < 1e-6
-    assert sum(l.startswith("percentage MV") for l in printed) == 3 and "STAGE 1 completed" in printed
+    assert sum(l.startswith("percentage MV") for l in out["lines"]) == 3
+    assert sum(l.startswith("Frame ") and l.endswith(" bpp") for l in out["lines"]) == 3
 
 
 def test_content_adaptive_search_reproduces_the_reference_script():
