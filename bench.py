@@ -397,13 +397,18 @@ def main():
         # done by now) and every rank leaves without waiting for the others.
         import threading
 
+        headline_line = dict(out)              # snapshot: the main thread keeps filling `out` while the timer runs
+
         def bail():
+            # the line survives (the timed region and its roofline are done), the STATUS does not: a hung collective or
+            # a dead rank must never read as success to the launcher
             if rank == 0:
-                out["pair_sharded"] = {"error": f"no result within {args.pair_shard_timeout_s} s (watchdog): a rank failed or "
-                                                f"a collective did not complete"}
-                out["bench_wall_s"] = time.time() - t_process
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                line = dict(headline_line)
+                line["pair_sharded"] = {"error": f"no result within {args.pair_shard_timeout_s} s (watchdog): a rank "
+                                                 f"failed or a collective did not complete"}
+                line["bench_wall_s"] = time.time() - t_process
+                print(json.dumps(line), flush=True)
+            os._exit(3)
         watchdog = threading.Timer(args.pair_shard_timeout_s, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -606,7 +611,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         import threading
-        leave = threading.Timer(60.0, lambda: os._exit(0))      # the line is out: never hang on the way out
+        leave = threading.Timer(60.0, lambda: os._exit(3))      # the line is out; a barrier that never returns is a failure
         leave.daemon = True
         leave.start()
         try:

@@ -27,6 +27,19 @@ extern "C" {
 #define PMCTF_ELAUNCH (-2)
 
 /* activation codes for conv epilogues / elementwise maps */
+/* Summation rule of a convolution (the argument `sum_rule`): the ORDER in which the products of one output element are
+ * added, which fixes its last bits.  Both are k-ordered fmaf chains over 16-channel blocks of the input, (ky, kx, ci)
+ * ascending inside a block:
+ *   PMCTF_SUM_CHAIN   acc = bias, then one chain through all blocks.  What ATen's CPU path computes for the 1x1 layers of
+ *                     the path whose reduction is one block (oneDNN jit_1x1) and for depthwise layers.
+ *   PMCTF_SUM_BLOCKS  every block a chain from zero, S_0 .. S_last; result (..((S_0 + bias) + S_1) + ..) + S_last.  What
+ *                     ATen's CPU path (oneDNN direct convolution) computes for every KH*KW > 1 layer, measured bit for bit
+ *                     (tools/aten_conv_rules.py).  The drop-in path uses it for every KH*KW > 1 layer with at most 16 input
+ *                     channels and for the multi-block layers of the signal path (motion estimation, motion codec, temporal
+ *                     and spatial lifting): the layers whose last bits decide symbols (profiles/round4_flip_attribution.md). */
+#define PMCTF_SUM_CHAIN 0
+#define PMCTF_SUM_BLOCKS 1
+
 #define PMCTF_ACT_NONE 0
 #define PMCTF_ACT_RELU 1    /* nn.ReLU                 video_net.py:77      */
 #define PMCTF_ACT_LEAKY 2   /* nn.LeakyReLU(slope)     video/layers.py:57-60, context_fusion_4step.py:13 */
@@ -81,6 +94,22 @@ int pmctf_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *bi
                           int N, int H, int W, int Cin, int Cout, int KH, int KW,
                           int stride, int pad_h, int pad_w, int act, float slope, void *stream);
 
+/* The same call with the summation rule (above; pmctf_conv2d_nhwc_f32 is PMCTF_SUM_CHAIN) and the launch-shape options of
+ * THIS launch handed over as arguments instead of read from the
+ * process-wide knobs (a field < 0, or opts == NULL, takes the knob of that name): "split" = "SPLIT", "msplit_px" =
+ * "MSPLIT_PX" above.  The captured launch plans of the drop-in path record their convolutions with their own values
+ * (two coders side by side fill each other's launch tails), and do so per launch: nothing process-wide changes while a
+ * plan is recorded, so a second model on another host thread keeps its own launch shapes.  Results never depend on them. */
+typedef struct pmctf_conv_launch_opts {
+    long split;      /* 0/1: cut the partial last round of 8x32 tiles into 4x16 tiles; < 0: process-wide knob */
+    long msplit_px;  /* planes with at most this many output pixels run one cout tile per workgroup; < 0: knob */
+} pmctf_conv_launch_opts;
+int pmctf_conv2d_nhwc_opts_f32(const float *x, const float *w_packed, const float *bias_packed,
+                               const float *res1, const float *res2, float *y,
+                               int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                               int stride, int pad_h, int pad_w, int act, float slope, int sum_rule,
+                               const pmctf_conv_launch_opts *opts, void *stream);
+
 /* Explicit-geometry form: output size (Ho,Wo) and top/left padding given by the caller; taps falling outside the
  * input read zero.  Used to evaluate a stride-1 convolution only at one 2x2 parity class of positions
  * (stride 2, pad = 1 - parity): the four-step coder needs the last ContextResidual conv and the 1x1 parameter head of
@@ -91,6 +120,12 @@ int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *w_packed, const floa
                                int stride, int pad_top, int pad_left, int Ho, int Wo, int act, float slope,
                                void *stream);
 
+int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *w_packed, const float *bias_packed,
+                                    const float *res1, const float *res2, float *y,
+                                    int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                    int stride, int pad_top, int pad_left, int Ho, int Wo, int act, float slope,
+                                    int sum_rule, const pmctf_conv_launch_opts *opts, void *stream);
+
 /* Same contract for Cin <= 4 (any Cin >= 1), plain OIHW weights on the device: direct convolution on the vector ALU
  * (first layers: PredictUpdate conv1 1->16 lifting_1d.py:38; PostProcess conv1 1->64 postprocessing.py:35; four-step
  * y_spatial_prior_k.0 1->112 and conv1_context 1|2->112 context_fusion_4step.py:48,63,73,83; masked 1->128
@@ -98,13 +133,13 @@ int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *w_packed, const floa
 int pmctf_conv2d_smallcin_f32(const float *x, const float *w_oihw, const float *bias,
                               const float *res1, const float *res2, float *y,
                               int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                              int stride, int pad_h, int pad_w, int act, float slope, void *stream);
+                              int stride, int pad_h, int pad_w, int act, float slope, int sum_rule, void *stream);
 
 /* PredictUpdate conv1 (pMCTF/layers/lifting_1d.py:38,44-45): 3x3, stride 1, pad 1, one input channel, Cout = 16
  * (other Cout: PMCTF_EINVAL).  y = conv(x); if y2 != NULL also y2 = act2(conv(x)) — the block needs both conv1 and
  * tanh(conv1).  x [N,H,W] plane, w OIHW on the device, y/y2 [N,H,W,16]. */
 int pmctf_conv3x3_cin1_dual_f32(const float *x, const float *w_oihw, const float *bias, float *y, float *y2,
-                                int N, int H, int W, int Cout, int act2, float slope, void *stream);
+                                int N, int H, int W, int Cout, int act2, float slope, int sum_rule, void *stream);
 
 /* KxK, stride 1, pad K/2, one or two output channels (PredictUpdate conv4 16->1 lifting_1d.py:41, PostProcess 64->1,
  * SpyNet 16->2 7x7): vector-ALU kernel, plain OIHW weights on the device, same sum order as pmctf_conv2d_nhwc_f32.
@@ -112,7 +147,7 @@ int pmctf_conv3x3_cin1_dual_f32(const float *x, const float *w_oihw, const float
 int pmctf_conv2d_fewcout_supported(int Cin, int Cout, int K);
 int pmctf_conv2d_fewcout_f32(const float *x, const float *w_oihw, const float *bias, const float *res1,
                              const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int K,
-                             int act, float slope, void *stream);
+                             int act, float slope, int sum_rule, void *stream);
 
 /* depthwise KxK conv, stride 1, pad K/2 (pMCTF/layers/video/layers.py:117-118); x,y [N,H,W,C], w [C,1,K,K] */
 int pmctf_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y,
@@ -198,11 +233,16 @@ int pmctf_conv3x3_split_geom_f32(const float *x, const uint16_t *w_packed, const
 int pmctf_predict_update_fused_f32(const float *x, const float *other, float *out, const float *w1, const float *b1,
                                    const float *w2_packed, const float *b2_packed, const float *w3_packed,
                                    const float *b3_packed, const float *w4, const float *b4, int N, int H, int W, int mode,
-                                   float c, float sign, float lw0, float lw1, float lw2, float lbias, void *stream);
+                                   float c, float sign, float lw0, float lw1, float lw2, float lbias, int sum_rule,
+                                   int skip_sum_rule, void *stream);
 
-/* ReflectionPad2d((0,0,1,1)) + 3x1 conv on NC single-channel planes (lifting_1d.py:98,105-106) */
+/* ReflectionPad2d((0,0,1,1)) + 3x1 conv on NC single-channel planes (lifting_1d.py:98,105-106).  sum_rule: one input
+ * channel = one block, so PMCTF_SUM_BLOCKS is "three fmaf from zero, bias last" (ATen's oneDNN path), PMCTF_SUM_CHAIN "bias
+ * first" — which is what ATen computes when the padded input of ONE plane has at most 20 480 elements and the reference
+ * tensor holds one plane (its im2col + gemv path; Convolution.cpp `use_mkldnn`): the caller passes the rule of the
+ * REFERENCE's tensor shape, not of a batch it may have stacked. */
 int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2, float bias,
-                         void *stream);
+                         int sum_rule, void *stream);
 /* nn.Upsample(scale_factor=2, mode="nearest") on NHWC (context_fusion_4step.py:50, long_context.py:50) */
 int pmctf_nearest_up2_nhwc_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 /* nn.PixelShuffle(2) on NHWC [N,H,W,4C] -> [N,2H,2W,C], optional activation (video/layers.py:34-38,96-104) */

@@ -22,7 +22,7 @@ inline unsigned nblocks(long n, int bs = 256) {
 __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                      const float *__restrict__ bias, const float *res1, const float *res2,
                                      float *y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int S,
-                                     int ph, int pw, int Ho, int Wo, int act, float slope) {
+                                     int ph, int pw, int Ho, int Wo, int act, float slope, int rule) {
     extern __shared__ float wl[];  // [tap][ci][co]
     const int taps = KH * KW;
     for (int i = threadIdx.x; i < Cout * Cin * taps; i += blockDim.x) {
@@ -38,7 +38,8 @@ __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *_
         const int ox = (int)(pm_mod(p, Wo)); p = pm_div(p, Wo);
         const int oy = (int)(pm_mod(p, Ho));
         const int n = (int)(pm_div(p, Ho));
-        float acc = bias ? bias[co] : 0.0f;
+        const float bv = bias ? bias[co] : 0.0f;
+        float acc = rule ? 0.0f : bv;            // rule 1 (one block, Cin <= 4): chain from zero, bias last
         for (int ky = 0; ky < KH; ++ky) {
             const int iy = oy * S + ky - ph;
             if (iy < 0 || iy >= H) continue;
@@ -50,6 +51,7 @@ __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *_
                 for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci * Cout], acc);
             }
         }
+        if (rule) acc = acc + bv;
         float v = pm::apply_act(acc, act, slope);
         if (res1) v = v + res1[idx];
         if (res2) v = v + res2[idx];
@@ -66,7 +68,7 @@ template <int K, int CIN>
 __global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                          const float *__restrict__ bias, const float *res1, const float *res2, float *y,
                                          int N, int H, int W, int Cout, int S, int ph, int pw, int Ho, int Wo, int act,
-                                         float slope) {
+                                         float slope, int rule) {
     const int ppp = 256 / Cout;                 // pixels per pass (Cout <= 256)
     const int co = threadIdx.x % Cout;
     const int slot = threadIdx.x / Cout;
@@ -83,7 +85,7 @@ __global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const floa
         const int r = p / Wo;
         const int oy = r % Ho;
         const int n = r / Ho;
-        float acc = b;
+        float acc = rule ? 0.0f : b;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             const int iy = oy * S + ky - ph;
@@ -97,6 +99,7 @@ __global__ void conv_smallcin_reg_kernel(const float *__restrict__ x, const floa
                 }
             }
         }
+        if (rule) acc = acc + b;
         float v = pm::apply_act(acc, act, slope);
         const size_t o = (size_t)p * Cout + co;
         if (res1) v = v + res1[o];
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
                                                                      const float *__restrict__ bias, const float *res1,
                                                                      const float *res2, float *y, int N, int H, int W,
                                                                      int Cout, int act, float slope, int Q, int G,
-                                                                     int wstrips_per_row, long total_items) {
+                                                                     int wstrips_per_row, long total_items, int rule) {
     constexpr int P = 8;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             if (sx + j < W) {
-                float4 acc = b;
+                float4 acc = rule ? make_float4(0.f, 0.f, 0.f, 0.f) : b;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
                             acc.z = __builtin_fmaf(v, wt.z, acc.z);
                             acc.w = __builtin_fmaf(v, wt.w, acc.w);
                         }
+                if (rule) { acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w; }
                 float4 o = make_float4(pm::apply_act(acc.x, act, slope), pm::apply_act(acc.y, act, slope),
                                        pm::apply_act(acc.z, act, slope), pm::apply_act(acc.w, act, slope));
                 const size_t oi = obase + (size_t)j * Cout;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
 // act2(conv) to a second tensor (the PredictUpdate block needs both conv1 and tanh(conv1)).
 __global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                  const float *__restrict__ bias, float *y, float *y2,
-                                                                 int N, int H, int W, int act2, float slope) {
+                                                                 int N, int H, int W, int act2, float slope, int rule) {
     const long total = (long)N * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(pm_mod(idx, W));
@@ -209,10 +213,11 @@ __global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int co = q * 4 + i;
-                float acc = bias ? bias[co] : 0.0f;
+                const float bv = bias ? bias[co] : 0.0f;
+                float acc = rule ? 0.0f : bv;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(in[t], w[co * 9 + t], acc);
-                v[i] = acc;
+                v[i] = rule ? acc + bv : acc;
             }
             *(float4 *)(y + idx * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
             if (y2)
@@ -230,7 +235,7 @@ template <int K, int CIN, int CO>
 __global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, const float *res1,
                                                                const float *res2, float *y, int N, int H, int W, int act,
-                                                               float slope) {
+                                                               float slope, int rule) {
     constexpr int P = K / 2;
     const long total = (long)N * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -238,9 +243,9 @@ __global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__re
         const long r = pm_div(idx, W);
         const int oy = (int)(pm_mod(r, H));
         const float *img = x + (r - oy) * W * CIN;
-        float acc[CO];
+        float acc[CO], tot[CO], bv[CO];
 #pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co] = bias ? bias[co] : 0.0f;
+        for (int co = 0; co < CO; ++co) { bv[co] = bias ? bias[co] : 0.0f; acc[co] = rule ? 0.0f : bv[co]; tot[co] = 0.0f; }
 #pragma unroll 1
         for (int cb = 0; cb < CIN / 16; ++cb) {
 #pragma unroll 1
@@ -269,10 +274,14 @@ __global__ __launch_bounds__(256) void conv_fewcout_pix_kernel(const float *__re
                             acc[co] = __builtin_fmaf(v[ci], w[((co * CIN + cb * 16 + ci) * K + ky) * K + kx], acc[co]);
                 }
             }
+            if (rule) {             // the chunk's sum is complete: (S_0 + bias), + S_1, ...
+#pragma unroll
+                for (int co = 0; co < CO; ++co) { tot[co] = cb == 0 ? acc[co] + bv[co] : tot[co] + acc[co]; acc[co] = 0.0f; }
+            }
         }
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-            float v = pm::apply_act(acc[co], act, slope);
+            float v = pm::apply_act(rule ? tot[co] : acc[co], act, slope);
             const long o = idx * CO + co;
             if (res1) v = v + res1[o];
             if (res2) v = v + res2[o];
@@ -291,7 +300,7 @@ template <int K, int CIN, int CO>
 __global__ __launch_bounds__(256) void conv_fewcout_lds_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                const float *__restrict__ bias, const float *res1,
                                                                const float *res2, float *y, int H, int W, int tiles_x,
-                                                               int tiles_y, int act, float slope) {
+                                                               int tiles_y, int act, float slope, int rule) {
     constexpr int P = K / 2, TH = 8, TW = 32, PH = TH + K - 1, PW = TW + K - 1, PS = 20;
     constexpr int E = PH * PW * 4, SLOTS = (E + 255) / 256, NCH = CIN / 16;
     extern __shared__ __attribute__((aligned(16))) float patch[];
@@ -303,9 +312,9 @@ __global__ __launch_bounds__(256) void conv_fewcout_lds_kernel(const float *__re
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int r = tid >> 5, c = tid & 31;
     const float *img = x + (long)n * H * W * CIN;
-    float acc[CO];
+    float acc[CO], tot[CO], bv[CO];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) acc[co] = bias ? bias[co] : 0.0f;
+    for (int co = 0; co < CO; ++co) { bv[co] = bias ? bias[co] : 0.0f; acc[co] = rule ? 0.0f : bv[co]; tot[co] = 0.0f; }
     // staging slots e = tid + 256*j: pixel e >> 2 of the patch, channel quad e & 3
     int goff[SLOTS];                                     // element offset inside the image, -1 = outside
 #pragma unroll
@@ -354,13 +363,17 @@ __global__ __launch_bounds__(256) void conv_fewcout_lds_kernel(const float *__re
                         acc[co] = __builtin_fmaf(v[ci], wc[((co * CIN + ci) * K + ky) * K + kx], acc[co]);
             }
         }
+        if (rule) {                 // the chunk's sum is complete: (S_0 + bias), + S_1, ...
+#pragma unroll
+            for (int co = 0; co < CO; ++co) { tot[co] = cb == 0 ? acc[co] + bv[co] : tot[co] + acc[co]; acc[co] = 0.0f; }
+        }
     }
     const int oy = oy0 + r, ox = ox0 + c;
     if (oy < H && ox < W) {
         const long idx = ((long)n * H + oy) * W + ox;
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-            float v = pm::apply_act(acc[co], act, slope);
+            float v = pm::apply_act(rule ? tot[co] : acc[co], act, slope);
             const long o = idx * CO + co;
             if (res1) v = v + res1[o];
             if (res2) v = v + res2[o];
@@ -631,10 +644,11 @@ __global__ void bilinear_down_kernel(const float *__restrict__ x, float *y, int 
 extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const float *bias, const float *res1,
                                          const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
                                          int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
-                                         void *stream) {
+                                         int sum_rule, void *stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || KH <= 0 || KW <= 0 ||
-        stride <= 0)
+        stride <= 0 || (sum_rule != 0 && sum_rule != 1))
         return PMCTF_EINVAL;
+    const int rule = sum_rule;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
     if (KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 32 && Cout <= 256 &&
@@ -648,7 +662,7 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         hipStream_t st = (hipStream_t)stream;
 #define PM_STRIP(C_)                                                                                                 \
     PM_LAUNCH((conv3x3_smallcin_strip_kernel<C_>), grid, block, 0, st, x, w, bias, res1, res2, y, N, H, W, Cout, act,  \
-              slope, Q, G, wstrips_per_row, total_items);                                                            \
+              slope, Q, G, wstrips_per_row, total_items, rule);                                                      \
     return launch_ok();
         if (Cin == 1) { PM_STRIP(1) }
         if (Cin == 2) { PM_STRIP(2) }
@@ -663,7 +677,7 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         hipStream_t st = (hipStream_t)stream;
 #define PM_SC(K_, C_)                                                                                               \
     PM_LAUNCH((conv_smallcin_reg_kernel<K_, C_>), grid, block, 0, st, x, w, bias, res1, res2, y, N, H, W, Cout, stride,  \
-              pad_h, pad_w, Ho, Wo, act, slope);                                                                    \
+              pad_h, pad_w, Ho, Wo, act, slope, rule);                                                              \
     return launch_ok();
         if (KH == 3 && Cin == 1) { PM_SC(3, 1) }
         if (KH == 3 && Cin == 2) { PM_SC(3, 2) }
@@ -677,17 +691,17 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
     unsigned g = nblocks(total);
     if (g > 8192) g = 8192;
     PM_LAUNCH(conv_smallcin_kernel, dim3(g), dim3(256), smem, (hipStream_t)stream, x, w, bias, res1, res2, y,
-                       N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo, act, slope);
+                       N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo, act, slope, rule);
     return launch_ok();
 }
 
 extern "C" int pmctf_conv3x3_cin1_dual_f32(const float *x, const float *w, const float *bias, float *y, float *y2, int N,
-                                           int H, int W, int Cout, int act2, float slope, void *stream) {
-    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cout != 16) return PMCTF_EINVAL;
+                                           int H, int W, int Cout, int act2, float slope, int sum_rule, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cout != 16 || (sum_rule != 0 && sum_rule != 1)) return PMCTF_EINVAL;
     unsigned g = nblocks((long)N * H * W);
     if (g > 16384) g = 16384;
     PM_LAUNCH(conv3x3_cin1_pix16_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, y2, N, H, W, act2,
-              slope);
+              slope, sum_rule);
     return launch_ok();
 }
 
@@ -697,8 +711,10 @@ extern "C" int pmctf_conv2d_fewcout_supported(int Cin, int Cout, int K) {
 
 extern "C" int pmctf_conv2d_fewcout_f32(const float *x, const float *w, const float *bias, const float *res1,
                                         const float *res2, float *y, int N, int H, int W, int Cin, int Cout, int K,
-                                        int act, float slope, void *stream) {
-    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || !pmctf_conv2d_fewcout_supported(Cin, Cout, K)) return PMCTF_EINVAL;
+                                        int act, float slope, int sum_rule, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || !pmctf_conv2d_fewcout_supported(Cin, Cout, K) ||
+        (sum_rule != 0 && sum_rule != 1))
+        return PMCTF_EINVAL;
     unsigned g = nblocks((long)N * H * W);
     if (g > 16384) g = 16384;
     hipStream_t st = (hipStream_t)stream;
@@ -709,11 +725,11 @@ extern "C" int pmctf_conv2d_fewcout_f32(const float *x, const float *w, const fl
     if (use_lds && tiles <= 0x7fffffffL && (long)H * W * CI_ < 0x7fffffffL) {                                         \
         const size_t smem = (size_t)(8 + K_ - 1) * (32 + K_ - 1) * 20 * sizeof(float);                                \
         PM_LAUNCH((conv_fewcout_lds_kernel<K_, CI_, CO_>), dim3((unsigned)tiles), dim3(256), smem, st, x, w, bias,     \
-                  res1, res2, y, H, W, tiles_x, tiles_y, act, slope);                                                 \
+                  res1, res2, y, H, W, tiles_x, tiles_y, act, slope, sum_rule);                                       \
         return launch_ok();                                                                                           \
     }                                                                                                                 \
     PM_LAUNCH((conv_fewcout_pix_kernel<K_, CI_, CO_>), dim3(g), dim3(256), 0, st, x, w, bias, res1, res2, y, N, H, W,   \
-              act, slope);                                                                                            \
+              act, slope, sum_rule);                                                                                  \
     return launch_ok();
     if (K == 3 && Cin == 16) { PM_FC(3, 16, 1) }
     if (K == 3 && Cin == 64) { PM_FC(3, 64, 1) }

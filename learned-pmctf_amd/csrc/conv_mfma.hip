@@ -4,7 +4,10 @@
 // call sites).  D[cout x pixel] += A[cout x k] * B[k x pixel] with
 // v_mfma_f32_16x16x4_f32, whose result is bit-for-bit a k-ordered fmaf chain, so the
 // sum order of the PM-F32 spec is reproduced exactly:
-//   acc = bias; for 16-channel chunk cb: for ky: for kx: for ci in chunk: fmaf
+//   rule 0 ("chain"):  acc = bias; for 16-channel chunk cb: for ky: for kx: for ci in chunk: fmaf
+//   rule 1 ("blocks"): per chunk a chain from zero S_cb; out = (..((S_0 + bias) + S_1) + ..) + S_last  — what ATen's CPU
+//                      path (oneDNN direct convolution) computes for KH*KW > 1; kernels instantiated with BSUM = true
+//                      (ConvArgs::bsum; every chunk's partial sum is added to a second accumulator set)
 // Workgroup = 4 waves (256 threads) = one TH x TW output tile of one image, all MT
 // 16-row cout tiles of one M-block.  Per chunk the input patch (tile + halo, 16
 // channels) is staged NHWC -> LDS once and shared by the 4 waves; each wave owns
@@ -39,10 +42,11 @@ struct ConvArgs {
     // mtp: cout tiles per packed M-block (the weight layout); a workgroup handles MT <= mtp of them, blockIdx.z
     // enumerates groups of MT tiles.  [oy_base, oy_end): output rows this launch covers.
     int mtp, oy_base, oy_end;
+    int bsum;       // summation rule: 0 chain from the bias, 1 per-chunk sums from zero added in turn (see the header)
 };
 
 // MT: cout tiles per workgroup, NT: pixel tiles per wave, TW16: 16-pixel segments per tile row.
-template <int MT, int NT, int TW16>
+template <int MT, int NT, int TW16, bool BSUM = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TW = TW16 * 16;
@@ -60,13 +64,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int iy0 = oy0 * a.S - a.pad_h, ix0 = ox0 * a.S - a.pad_w;
     const int taps = a.KH * a.KW;
 
-    // accumulators start at the bias: acc = bias[co]
+    // rule 0: accumulators start at the bias: acc = bias[co]; rule 1 (BSUM): every chunk starts from zero
     f32x4 acc[MT][NT];
+    f32x4 tot[BSUM ? MT : 1][BSUM ? NT : 1];
     {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = BSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
         }
@@ -123,6 +128,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
         }
+        if constexpr (BSUM) {       // S_cb is complete: (S_0 + bias), then + S_1, + S_2 ...
+            const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    tot[mt][nt] = cb == 0 ? acc[mt][nt] + b : tot[mt][nt] + acc[mt][nt];
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+    if constexpr (BSUM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
     }
 
     // epilogue: lane holds couts co..co+3 of pixel (lane&15) of each segment
@@ -752,7 +775,7 @@ _Pragma("unroll")
 // slots on address arithmetic when MT = 1).  Same sums, same order.
 // NT = 4: 8x32 tiles (a wave owns two rows); NT = 1: 4x16 tiles (a wave owns one 16-pixel row) for the small pyramid
 // levels, where the generic kernel waits for every tap's weights (105 us on a 36x60 plane that holds 3 us of work).
-template <int MT, int NT = 4>
+template <int MT, int NT = 4, bool BSUM = false>
 __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
     constexpr int K = 7, TH = NT == 4 ? 8 : 4, TW = NT == 4 ? 32 : 16, LH = TH + K - 1, LW = TW + K - 1;
     constexpr int BUFSZ = LH * LW * CP;
@@ -770,11 +793,12 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
     const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
 
     f32x4 acc[MT][NT];
+    f32x4 tot[BSUM ? MT : 1][BSUM ? NT : 1];            // rule 1: running output, a chunk's sum is added when complete
     {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = BSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
         }
@@ -883,8 +907,26 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
         }
+        if constexpr (BSUM) {
+            const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    tot[mt][nt] = cb == 0 ? acc[mt][nt] + b : tot[mt][nt] + acc[mt][nt];
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
         if (more) stash((cb + 1) & 1);
         __syncthreads();
+    }
+    if constexpr (BSUM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
     }
 
     PM_EPILOGUE(a,
@@ -1092,7 +1134,7 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
         if (more) fetch(tile + stride);
         f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = a.bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float *bb = cur + ((t / 3) * LW + (t % 3)) * CP;
@@ -1105,6 +1147,10 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
             }
+        }
+        if (a.bsum) {           // rule 1, one chunk: the chain ran from zero, the bias is added last
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] + bias;
         }
         {
             const int n = tile / per_img, r = tile - n * per_img;
@@ -1254,7 +1300,7 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
         if (prev >= 0) finish(prev);
         if (tile + stride < t_end) fetch(tile + stride);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = bias;
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = a.bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float *bb = wlds + ((t / 3) * LW + (t % 3)) * CP + boff;
@@ -1267,6 +1313,10 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
             }
+        }
+        if (a.bsum) {           // rule 1, one chunk: the chain ran from zero, the bias is added last
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] + bias;
         }
         prev = tile;
     }
@@ -1470,6 +1520,28 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     const size_t smem = (size_t)LH * LW * CP * sizeof(float);
     if (smem > 160 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
+    if (a.bsum) {
+        // rule 1 (per-chunk sums): the 7x7 pipelined kernel where it applies (SpyNet), else the single-buffer kernel;
+        // the specialised 3x3 / wave-private kernels carry rule 0 only (their layers of the path that need rule 1 have at
+        // most 64 couts and are a few per cent of the work)
+        if constexpr (((NT == 4 && TW16 == 2) || (NT == 1 && TW16 == 1)) && MT <= 4) {
+            if (a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 && knob("K77") != 0 &&
+                (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+                static std::once_flag once_7b;
+                allow_big_lds(conv7x7s1_pipe_kernel<MT, NT, true>, once_7b);
+                CONV_LAUNCH((conv7x7s1_pipe_kernel<MT, NT, true>), grid, dim3(256), 2 * smem, st, b);
+                return pm_launch_status();
+            }
+        }
+        if constexpr (MT <= 4 || NT <= 2) {
+            static std::once_flag once_sb;
+            allow_big_lds(conv_mfma_kernel<MT, NT, TW16, true>, once_sb);
+            CONV_LAUNCH((conv_mfma_kernel<MT, NT, TW16, true>), grid, dim3(256), smem, st, b);
+            return pm_launch_status();
+        } else {
+            return launch<MT, 2, 1>(a, gz, st, r0, r1);     // wide M-blocks: 2 segments per wave keep both accumulator sets in registers
+        }
+    }
     if constexpr (NT == 4 && TW16 == 2) {   // barrier-free wave-private variant (8x32 workgroup tile = 2x2 wave tiles of 4x16)
         if ((MT >= 4 || ((MT == 2 || (MT == 1 && knob("WAVE_SMALL") != 0)) && a.KH == 3 && a.KW == 3 && a.S == 1)) && wave_eligible(a)) {
             const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
@@ -1558,9 +1630,18 @@ int launch_res(const ConvArgs &a, int gz, hipStream_t st) {
     return pm_launch_status();
 }
 
+// Launch-shape options of ONE call, resolved: a caller's pmctf_conv_launch_opts field >= 0, else the process-wide knob.
+struct LaunchOpts { long split, msplit_px; };
+inline LaunchOpts resolve_opts(const pmctf_conv_launch_opts *o) {
+    LaunchOpts r;
+    r.split = (o && o->split >= 0) ? o->split : knob("SPLIT");
+    r.msplit_px = (o && o->msplit_px >= 0) ? o->msplit_px : knob("MSPLIT_PX");
+    return r;
+}
+
 // MTP = cout tiles per packed M-block (fixed by the weight layout); chooses the tile shape and how the launch is cut.
 template <int MTP>
-int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
+int dispatch_tile(ConvArgs a, int MB, hipStream_t st, const LaunchOpts &lo) {
     a.mtp = MTP;
     const long px = (long)a.Ho * a.Wo * a.N;
     const long force_nt = knob("NT");
@@ -1599,17 +1680,17 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     }
     // (1) small planes: too few 16-pixel segments to occupy 1024 SIMDs with whole M-blocks -> one cout tile per
     //     workgroup, MTP x more (and MTP x shorter) workgroups.  Same sums, same order.
-    const long msplit_px = knob("MSPLIT_PX");
+    const long msplit_px = lo.msplit_px;
     // stride-2 3x3 with 112 couts (the quarter-resolution context convolutions on the small DWT levels): the specialised
     // pipelined kernel with all cout tiles per workgroup beats the cout-split generic one from 8 000 output pixels up
     // (2x288x480 -> 2x144x240: 324 -> 177 us; tools/bench_conv.py "s2small")
     const bool s2_whole = MTP >= 7 && a.S == 2 && a.KH == 3 && a.KW == 3 && (a.Cin % CB) == 0 && knob("K33") != 0 && px >= 8000;
     if (MTP >= 2 && px <= msplit_px && !s2_whole) {
-        if (knob("RES") == 1) {
+        if (knob("RES") == 1 && !a.bsum) {
             const int rc = launch_res<1>(a, MTP * MB, st);
             if (rc != PMCTF_EINVAL) return rc;
         }
-        if (knob("RES") == 2) {
+        if (knob("RES") == 2 && !a.bsum) {
             const int rc = launch_res<MTP>(a, MB, st);
             if (rc != PMCTF_EINVAL) return rc;
         }
@@ -1633,7 +1714,7 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st) {
     // (2) large planes, stride 1: 8x32 tiles.  The wave-private kernel holds 2 workgroups per CU = 512 slots; rows
     //     that fill whole rounds of 512 go to it, the remaining rows (a partial round) are cut 4x finer (4x16 tiles)
     //     so the tail of the launch costs a quarter of a round instead of a full one.
-    const bool split = knob("SPLIT") != 0;
+    const bool split = lo.split != 0;
     // without the cut (launch plans: another stream fills the tail of a launch) the 8x32-tile kernel pays from 200 000
     // pixels on (2x288x480), measured on the harness loop; 1x288x480 (1.05 rounds of 512 workgroups) stays on 4x16 tiles
     const long big_px = split ? knob("BIGPX") : knob("BIGPX_NOSPLIT");
@@ -1753,12 +1834,14 @@ extern "C" int pmctf_conv2d_pack_weights(const float *w, const float *bias, int 
     return PMCTF_OK;
 }
 
-extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const float *bp, const float *res1,
-                                          const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
-                                          int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
-                                          int act, float slope, void *stream) {
+extern "C" int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                               const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                               int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                                               int act, float slope, int sum_rule, const pmctf_conv_launch_opts *opts,
+                                               void *stream) {
     if (!x || !wp || !bp || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 || Ho <= 0 || Wo <= 0)
+        KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 || Ho <= 0 || Wo <= 0 ||
+        (sum_rule != PMCTF_SUM_CHAIN && sum_rule != PMCTF_SUM_BLOCKS))
         return PMCTF_EINVAL;
     ConvArgs a;
     a.x = x; a.wp = wp; a.bp = bp; a.res1 = res1; a.res2 = res2; a.y = y;
@@ -1770,23 +1853,33 @@ extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const
     a.act = act; a.slope = slope;
     a.tiles_x = a.tiles_y = 0;
     a.mtp = 1; a.oy_base = 0; a.oy_end = Ho;
+    a.bsum = sum_rule == PMCTF_SUM_BLOCKS ? 1 : 0;
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;
     g_last_len = 0;
     g_last_launch[0] = 0;
-    if (KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
+    if (!a.bsum && KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
         knob("K11") != 0 && MT * MB >= knob("K11_MIN_TILES")) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
         a.mtp = MT;
         return launch_1x1(a, MT * MB, st);
     }
+    const LaunchOpts lo = resolve_opts(opts);
     switch (MT) {
-    case 1: return dispatch_tile<1>(a, MB, st);
-    case 2: return dispatch_tile<2>(a, MB, st);
-    case 4: return dispatch_tile<4>(a, MB, st);
-    case 7: return dispatch_tile<7>(a, MB, st);
-    default: return dispatch_tile<8>(a, MB, st);
+    case 1: return dispatch_tile<1>(a, MB, st, lo);
+    case 2: return dispatch_tile<2>(a, MB, st, lo);
+    case 4: return dispatch_tile<4>(a, MB, st, lo);
+    case 7: return dispatch_tile<7>(a, MB, st, lo);
+    default: return dispatch_tile<8>(a, MB, st, lo);
     }
+}
+
+extern "C" int pmctf_conv2d_nhwc_geom_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                          const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                                          int act, float slope, void *stream) {
+    return pmctf_conv2d_nhwc_geom_opts_f32(x, wp, bp, res1, res2, y, N, H, W, Cin, Cout, KH, KW, stride, pad_top, pad_left,
+                                           Ho, Wo, act, slope, PMCTF_SUM_CHAIN, nullptr, stream);
 }
 
 extern "C" int pmctf_conv2d_last_launch(char *buf, int capacity) {
@@ -1802,6 +1895,17 @@ extern "C" int pmctf_conv2d_nhwc_f32(const float *x, const float *wp, const floa
     if (stride <= 0 || KH <= 0 || KW <= 0) return PMCTF_EINVAL;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1;
     const int Wo = (W + 2 * pad_w - KW) / stride + 1;
-    return pmctf_conv2d_nhwc_geom_f32(x, wp, bp, res1, res2, y, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho, Wo,
-                                      act, slope, stream);
+    return pmctf_conv2d_nhwc_geom_opts_f32(x, wp, bp, res1, res2, y, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho,
+                                           Wo, act, slope, PMCTF_SUM_CHAIN, nullptr, stream);
+}
+
+extern "C" int pmctf_conv2d_nhwc_opts_f32(const float *x, const float *wp, const float *bp, const float *res1,
+                                          const float *res2, float *y, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
+                                          int sum_rule, const pmctf_conv_launch_opts *opts, void *stream) {
+    if (stride <= 0 || KH <= 0 || KW <= 0) return PMCTF_EINVAL;
+    const int Ho = (H + 2 * pad_h - KH) / stride + 1;
+    const int Wo = (W + 2 * pad_w - KW) / stride + 1;
+    return pmctf_conv2d_nhwc_geom_opts_f32(x, wp, bp, res1, res2, y, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, Ho,
+                                           Wo, act, slope, sum_rule, opts, stream);
 }

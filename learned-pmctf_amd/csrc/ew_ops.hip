@@ -159,9 +159,11 @@ __global__ void spynet_pack8_kernel(const float *__restrict__ im1, const float *
 }
 
 // reflectionPadSkip + 3x1 conv along H on single-channel planes (lifting_1d.py:98,105-106):
-// acc = bias; acc = fmaf(x[refl(y-1)], w0, acc); acc = fmaf(x[y], w1, acc); acc = fmaf(x[refl(y+1)], w2, acc)
+// rule 0: acc = bias; acc = fmaf(x[refl(y-1)], w0, acc); acc = fmaf(x[y], w1, acc); acc = fmaf(x[refl(y+1)], w2, acc)
+// rule 1: the same three fmaf from zero, the bias added last (what ATen's oneDNN path computes; rule 0 is what its
+//         im2col + gemv path computes for the planes that take it, see pmctf_hip.h)
 __global__ void lift_skip3_kernel(const float *__restrict__ x, float *y, int NC, int H, int W, float w0, float w1,
-                                  float w2, float bias) {
+                                  float w2, float bias, int rule) {
     const long total = (long)NC * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int xw = (int)(pm_mod(idx, W));
@@ -171,11 +173,11 @@ __global__ void lift_skip3_kernel(const float *__restrict__ x, float *y, int NC,
         const int ym = yy == 0 ? 1 : yy - 1;
         const int yp = yy == H - 1 ? H - 2 : yy + 1;
         const float *pl = x + nc * H * W;
-        float acc = bias;
+        float acc = rule ? 0.0f : bias;
         acc = __builtin_fmaf(pl[(long)ym * W + xw], w0, acc);
         acc = __builtin_fmaf(pl[(long)yy * W + xw], w1, acc);
         acc = __builtin_fmaf(pl[(long)yp * W + xw], w2, acc);
-        y[idx] = acc;
+        y[idx] = rule ? acc + bias : acc;
     }
 }
 
@@ -483,10 +485,10 @@ extern "C" int pmctf_spynet_pack8_f32(const float *im1, const float *warped, con
 }
 
 extern "C" int pmctf_lift_skip3_f32(const float *x, float *y, int NC, int H, int W, float w0, float w1, float w2,
-                                    float bias, void *stream) {
-    if (!x || !y || NC <= 0 || H < 2 || W <= 0) return PMCTF_EINVAL;
+                                    float bias, int sum_rule, void *stream) {
+    if (!x || !y || NC <= 0 || H < 2 || W <= 0 || (sum_rule != 0 && sum_rule != 1)) return PMCTF_EINVAL;
     PM_LAUNCH(lift_skip3_kernel, dim3(grid_for((long)NC * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, NC,
-                       H, W, w0, w1, w2, bias);
+                       H, W, w0, w1, w2, bias, sum_rule);
     return launch_ok();
 }
 

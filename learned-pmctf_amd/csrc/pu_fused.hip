@@ -15,8 +15,10 @@
 // lives in LDS (74.5 KB, two workgroups per CU so that the vector-ALU phases of one overlap the matrix phases of the
 // other):   in[16x40] -> (VALU) tanh(c1) on 14x38 -> (MFMA) tanh(conv2) on 12x36 -> (MFMA) conv3 + c1 on 10x34 ->
 // (VALU) conv4 on 8x32.  Values outside the image are stored as 0: every layer zero-pads its own input.
-// PM-F32 order, identical to the separate kernels (and to oracle/c/pm_ops.c): acc = bias; ky, kx, ci ascending fmaf;
-// v_mfma_f32_16x16x4_f32 is that chain bit for bit.  The residual c1 of layer 3 is re-evaluated from the input tile
+// PM-F32 order, identical to the separate kernels (and to oracle/c/pm_ops.c): ky, kx, ci ascending fmaf, the chain starting
+// at the bias (rule 0) or at zero with the bias added last (rule 1 — every layer here has at most 16 input channels, one
+// block; `rule` for the four CNN layers, `skip_rule` for the 3x1 lifting filter, which ATen evaluates through another path
+// on small planes); v_mfma_f32_16x16x4_f32 is that chain bit for bit.  The residual c1 of layer 3 is re-evaluated from the input tile
 // with the same nine fmaf, so no second copy of c1 is kept.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,6 +49,7 @@ struct PuArgs {
     const float *w4, *b4;        // (1,16,3,3) OIHW + (1)
     int N, H, W, tiles_x, tiles_y, mode;
     float c, sign, lw0, lw1, lw2, lb;
+    int rule, skip_rule;
 };
 
 // one 16->16 3x3 layer on the matrix cores: src (row stride SW pixels, CP words per pixel) -> D fragments per segment.
@@ -54,7 +57,7 @@ struct PuArgs {
 // back to back (a single chain waits 40 cycles per dependent v_mfma_f32_16x16x4_f32) and cover the LDS read latency.
 template <typename Epilogue>
 __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int npix, const float *wp, const float *bp,
-                                           int wave, int lane, Epilogue epi) {
+                                           int wave, int lane, int rule, Epilogue epi) {
     f32x4 af[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) af[t] = *(const f32x4 *)(wp + t * 256 + lane * 4);
@@ -70,7 +73,8 @@ __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int
         const int r1 = idx1 / RW, c1 = idx1 - r1 * RW;
         const float *p0 = src + (r0 * SW + c0) * CP + (lane >> 4);
         const float *p1 = src + (r1 * SW + c1) * CP + (lane >> 4);
-        f32x4 acc0 = bias, acc1 = bias;
+        const f32x4 start = rule ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
+        f32x4 acc0 = start, acc1 = start;
         if (two) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -93,6 +97,7 @@ __device__ __forceinline__ void mfma_layer(const float *src, int SW, int RW, int
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], p0[toff + ks * 4], acc0, 0, 0, 0);
             }
         }
+        if (rule) { acc0 = acc0 + bias; acc1 = acc1 + bias; }
         if (live0) epi(idx0, r0, c0, acc0);
         if (live1) epi(idx1, r1, c1, acc1);
     }
@@ -134,10 +139,11 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
             } else {
                 const int ym = gy == 0 ? 1 : gy - 1;
                 const int yp = gy == a.H - 1 ? a.H - 2 : gy + 1;
-                float acc = a.lb;
+                float acc = a.skip_rule ? 0.0f : a.lb;
                 acc = __builtin_fmaf(xp[(long)ym * a.W + gx], a.lw0, acc);
                 acc = __builtin_fmaf(xp[(long)gy * a.W + gx], a.lw1, acc);
                 acc = __builtin_fmaf(xp[(long)yp * a.W + gx], a.lw2, acc);
+                if (a.skip_rule) acc = acc + a.lb;
                 s = acc;
                 v = acc / 256.0f;
             }
@@ -179,9 +185,10 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float acc = bq[i];
+                float acc = a.rule ? 0.0f : bq[i];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[j][t], wq[i][t], acc);
+                if (a.rule) acc = acc + bq[i];
                 v[i] = ok[j] ? pm::tanhf_(acc) : 0.0f;
             }
             float2 *dst = (float2 *)(A1 + idx * CP + 4 * q);
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
     PU_STAMP(1);
 
     // ---- P2 (matrix cores): tanh(conv2(tanh c1)) on the 12x36 region
-    mfma_layer(A1, R1W, R2W, N2, a.w2p, a.b2p, wave, lane, [&](int idx, int r, int c, f32x4 acc) {
+    mfma_layer(A1, R1W, R2W, N2, a.w2p, a.b2p, wave, lane, a.rule, [&](int idx, int r, int c, f32x4 acc) {
         const int gy = y0 - 2 + r, gx = x0 - 2 + c;
         const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         float v[4];
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) w1g[i][t] = a.w1[co * 9 + t];
     }
-    mfma_layer(A2, R2W, R3W, N3, a.w3p, a.b3p, wave, lane, [&](int idx, int r, int c, f32x4 acc) {
+    mfma_layer(A2, R2W, R3W, N3, a.w3p, a.b3p, wave, lane, a.rule, [&](int idx, int r, int c, f32x4 acc) {
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
         const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -231,9 +238,10 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
             for (int t = 0; t < 9; ++t) iv[t] = in[(r + 2 + t / 3) * IW + c + 2 + t % 3];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float c1 = b1g[i];
+                float c1 = a.rule ? 0.0f : b1g[i];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) c1 = __builtin_fmaf(iv[t], w1g[i][t], c1);
+                if (a.rule) c1 = c1 + b1g[i];
                 v[i] = acc[i] + c1;
             }
         }
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         const int r = tid >> 5, c = tid & 31;
         const int gy = y0 + r, gx = x0 + c;
         if (gy < a.H && gx < a.W) {
-            float acc = a.b4[0];
+            float acc = a.rule ? 0.0f : a.b4[0];
 #pragma unroll 1
             for (int t = 0; t < 9; ++t) {                       // one tap's 16 weights at a time stay scalar
                 const float2 *p = (const float2 *)(A3 + ((r + t / 3) * R3W + c + t % 3) * CP);
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
                     acc = __builtin_fmaf(v.y, a.w4[(2 * q + 1) * 9 + t], acc);
                 }
             }
+            if (a.rule) acc = acc + a.b4[0];
             const long o = plane + (long)gy * a.W + gx;
             const int e = (r + 4) * IW + c + 4;
             float res;
@@ -281,14 +290,17 @@ extern "C" int pmctf_predict_update_fused_f32(const float *x, const float *other
                                               const float *b1, const float *w2_packed, const float *b2_packed,
                                               const float *w3_packed, const float *b3_packed, const float *w4,
                                               const float *b4, int N, int H, int W, int mode, float c, float sign,
-                                              float lw0, float lw1, float lw2, float lbias, void *stream) {
+                                              float lw0, float lw1, float lw2, float lbias, int sum_rule,
+                                              int skip_sum_rule, void *stream) {
     if (!x || !out || !w1 || !b1 || !w2_packed || !b2_packed || !w3_packed || !b3_packed || !w4 || !b4 || N <= 0 ||
-        H <= 0 || W <= 0 || (mode != 0 && mode != 1) || (mode == 1 && (!other || H < 2)))
+        H <= 0 || W <= 0 || (mode != 0 && mode != 1) || (mode == 1 && (!other || H < 2)) ||
+        (sum_rule != 0 && sum_rule != 1) || (skip_sum_rule != 0 && skip_sum_rule != 1))
         return PMCTF_EINVAL;
     PuArgs a;
     a.x = x; a.other = other; a.out = out; a.w1 = w1; a.b1 = b1; a.w2p = w2_packed; a.b2p = b2_packed;
     a.w3p = w3_packed; a.b3p = b3_packed; a.w4 = w4; a.b4 = b4;
     a.N = N; a.H = H; a.W = W; a.mode = mode; a.c = c; a.sign = sign; a.lw0 = lw0; a.lw1 = lw1; a.lw2 = lw2; a.lb = lbias;
+    a.rule = sum_rule; a.skip_rule = skip_sum_rule;
     a.tiles_x = (W + TW - 1) / TW;
     a.tiles_y = (H + TH - 1) / TH;
     const long blocks = (long)a.tiles_x * a.tiles_y * N;

@@ -168,10 +168,23 @@ class RangeCoderPool:
 
 
 class CaptureGate:
-    """Stream capture tolerates no device synchronisation, pinned allocation or allocator growth anywhere in the process
-    while it lasts, so a host thread that records a launch plan needs the engine to itself: model entry points hold the
-    gate shared, a recording holds it exclusively (it gives up its own shared hold first, so two recorders cannot wait
-    for each other).  With one host thread — the reference harness — the gate is never contended."""
+    """Stream capture tolerates no device synchronisation, pinned allocation or allocator growth anywhere in the PROCESS
+    while it lasts, so a host thread that records a launch plan needs the device to itself: the entry points of every
+    model on that device hold ONE gate shared (CaptureGate.of(device)), a recording holds it exclusively (it gives up its
+    own shared hold first, so two recorders cannot wait for each other).  With one host thread — the reference harness,
+    also when it runs several models one after the other — the gate is never contended; with one model per host thread
+    (an RD sweep run in parallel) a recording waits for the other models' calls in flight and they wait for it."""
+    _per_device = {}
+    _per_device_lock = threading.Lock()
+
+    @classmethod
+    def of(cls, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        with cls._per_device_lock:
+            gate = cls._per_device.get(key)
+            if gate is None:
+                gate = cls._per_device[key] = cls()
+            return gate
 
     def __init__(self):
         self.cond = threading.Condition()
@@ -268,8 +281,14 @@ class HipEngine:
         self.pair_plans = {}
         self._plan_ctx = {}             # per host thread: graph memory pools and streams of its launch plans
         self.plan_timing = None         # a list: launch plans append (start, motion, luma, chroma, luma syn, chroma syn) events
-        self.gate = CaptureGate()
+        self._ref_tls = threading.local()   # .planes: planes per REFERENCE tensor while a stacked batch is being coded
+        self.gate = CaptureGate.of(self.dev)
         self.host_threads = set()
+        # launch-shape options the plans' convolutions carry per launch (see pair_plan.PairPlan.__init__)
+        self.plan_launch_opts = ops.ConvLaunchOpts(int(os.environ.get("PMCTF_PLAN_SPLIT", "0")),
+                                                   int(os.environ.get("PMCTF_PLAN_MSPLIT_PX", "40000")))
+        from . import pair_plan
+        pair_plan.RESOURCES.drain()     # a safe point: what dropped models left behind goes now
         self.syn_after_analysis = os.environ.get("PMCTF_SYN_AFTER_ANALYSIS", "1") != "0"
         self.stats = {"enqueue_s": 0.0, "gpu_done_s": 0.0, "pair_s": 0.0, "pairs": 0}
         self.profile_host = False
@@ -289,22 +308,62 @@ class HipEngine:
                 "streams": (torch.cuda.Stream(device=self.dev, priority=prio),
                             torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("PMCTF_CHROMA_PRIORITY", "0")))),
                 "capture": torch.cuda.Stream(device=self.dev)}
+            from . import pair_plan
+            pair_plan.RESOURCES.adopt(self, dict(ctx))       # the streams outlive the engine until the next safe point
         return ctx
 
     def release(self):
         """drop the captured launch plans (their graphs hold device memory pools) — called when the model replaces the
-        engine"""
-        torch.cuda.synchronize(self.dev)
+        engine or goes away.  May run at ANY moment (a finaliser): it only lets go of the plans; their device objects
+        are destroyed by pair_plan.RESOURCES at the next point where no capture can be open — here, if that is now."""
+        from . import pair_plan
         self.pair_plans.clear()
         self._plan_ctx.clear()
+        pair_plan.RESOURCES.drain()
 
     # ------------------------------------------------------------------ packed layers
+    SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
+
+    @classmethod
+    def sum_rule(cls, p, weight):
+        """Summation rule of the convolution with parameter key p (include/pmctf_hip.h PMCTF_SUM_*).
+        KH*KW > 1 layers of the SIGNAL path — motion estimation, motion codec, temporal lifting, the spatial lifting DWT
+        and its inverse: everything a coefficient value or the motion field is computed by — add their products the way
+        ATen's CPU convolution does (per 16-channel block from zero, block sums in turn, bias after the first): measured,
+        the last bits of exactly these layers decide the symbols that differed from the reference's
+        (profiles/round4_flip_attribution.md).  The entropy-parameter networks, post-processing, every 1x1 and depthwise
+        layer keep the single chain from the bias (which for 1x1 / depthwise IS ATen's order)."""
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        if kh * kw > 1 and (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+            return ops.SUM_BLOCKS
+        return ops.SUM_CHAIN
+
+    @contextlib.contextmanager
+    def reference_planes(self, n):
+        """inside the block the calling thread codes a batch of stacked reference tensors of n planes each (the
+        stage-batched schedule): shape-dependent choices the reference makes per tensor follow n, not the stacked batch"""
+        prev = getattr(self._ref_tls, "planes", None)
+        self._ref_tls.planes = n
+        try:
+            yield
+        finally:
+            self._ref_tls.planes = prev
+
+    @staticmethod
+    def lift_skip_rule(ref_planes, H, W):
+        """Rule of a lifting step's 3x1 filter on planes of H x W (one input channel = one block).  ATen evaluates the
+        layer through oneDNN (bias last) unless its `use_mkldnn` test fails — a reference tensor of ONE plane whose
+        reflect-padded input has at most 20 480 elements — in which case im2col + gemv starts from the bias.
+        ref_planes: planes in the REFERENCE's tensor (1 luma, 2 chroma), whatever batch this build has stacked."""
+        return ops.SUM_CHAIN if ref_planes == 1 and (H + 2) * W <= 20480 else ops.SUM_BLOCKS
+
     def conv(self, p, stride=1, padding=0):
         key = (p, stride, padding)
         c = self._convs.get(key)
         if c is None:
-            c = ops.Conv2d(self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride, (padding, padding), self.dev,
-                           split=self.nsplit)
+            w = self.sd[p + ".weight"]
+            c = ops.Conv2d(w, self.sd.get(p + ".bias"), stride, (padding, padding), self.dev,
+                           split=self.nsplit, rule=self.sum_rule(p, w))
             torch.cuda.synchronize(self.dev)      # packed weights are used from several streams later
             self._convs[key] = c
         return c
@@ -593,22 +652,26 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ a10 learned lifting DWT
-    def lift_branch(self, wt, conv_name, pu_name, x):
+    def lift_branch(self, wt, conv_name, pu_name, x, skip_rule):
         """skip + 0.1 * 256 * PU(skip/256)   (lifting_1d.py:105-110)"""
         w = self.sd[f"{wt}.{conv_name}.weight"].reshape(-1)
         b = self.sd[f"{wt}.{conv_name}.bias"].reshape(-1)
-        skip = ops.lift_skip3(x, w.tolist(), float(b[0]))
+        skip = ops.lift_skip3(x, w.tolist(), float(b[0]), skip_rule)
         pu = self.predict_update(f"{wt}.{pu_name}", ew(EW_DIVS, skip, alpha=256.0))
         return ew(EW_ADD_MULS2, skip, pu, 256.0, 0.1)
 
-    def lift_step(self, wt, conv_name, pu_name, src, other, sign):
-        """other + sign * branch(src): one lifting step (lifting_1d.py:105-118 forward, :150-163 backward)"""
+    def lift_step(self, wt, conv_name, pu_name, src, other, sign, ref_planes=None):
+        """other + sign * branch(src): one lifting step (lifting_1d.py:105-118 forward, :150-163 backward).
+        ref_planes: planes per tensor in the reference (None: this tensor's own batch)."""
+        if ref_planes is None:
+            ref_planes = getattr(self._ref_tls, "planes", None)
+        skip_rule = self.lift_skip_rule(src.shape[0] if ref_planes is None else ref_planes, src.shape[2], src.shape[3])
         if self.use_pu_fused(src) and src.shape[2] >= 2:
             w = self.sd[f"{wt}.{conv_name}.weight"].reshape(-1).tolist()
             b = float(self.sd[f"{wt}.{conv_name}.bias"].reshape(-1)[0])
             return ops.predict_update_fused(src, other, self.pu_convs(f"{wt}.{pu_name}"), 1, sign=sign,
-                                            lift=(w[0], w[1], w[2], b))
-        return ew(EW_ADD if sign > 0 else EW_SUB, other, self.lift_branch(wt, conv_name, pu_name, src))
+                                            lift=(w[0], w[1], w[2], b), skip_rule=skip_rule)
+        return ew(EW_ADD if sign > 0 else EW_SUB, other, self.lift_branch(wt, conv_name, pu_name, src, skip_rule))
 
     def forward_lift(self, wt, x):
         """iWave1D.forward_lift along H (lifting_1d.py:103-145); x plane (N,1,H,W) -> l, h (N,1,H/2,W)"""
@@ -931,20 +994,23 @@ class HipEngine:
             ev.record()
             self.lt_event, self.lt_tensor, self.lt_stream = ev, L_t, torch.cuda.current_stream(self.dev).cuda_stream
         qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
-        H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, False, defer=True, per_push=True)
+        with self.reference_planes(n):
+            H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, False, defer=True, per_push=True)
         out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "L_t_hat": None}
         if on_stream is not None:
             on_stream("H", h_stream, n)
         L_syn = None
         if code_lt:
-            L_syn, l_stream = self.pwave_compress("lp_coder", L_t, q_index, None, False, defer=True, per_push=True)
+            with self.reference_planes(n):
+                L_syn, l_stream = self.pwave_compress("lp_coder", L_t, q_index, None, False, defer=True, per_push=True)
             if on_stream is not None:
                 on_stream("L", l_stream, n)
 
         def finish():
-            out["H_t_hat"] = H_syn()
-            if L_syn is not None:
-                out["L_t_hat"] = L_syn()
+            with self.reference_planes(n):
+                out["H_t_hat"] = H_syn()
+                if L_syn is not None:
+                    out["L_t_hat"] = L_syn()
             return out
         out["finish"] = finish
         return out

@@ -25,10 +25,12 @@ _SIGS = {
     "pmctf_conv2d_get_option": (C.c_long, [C.c_char_p]),
     "pmctf_conv2d_nhwc_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
     "pmctf_conv2d_nhwc_geom_f32": (ci, [vp] * 6 + [ci] * 13 + [cf, vp]),
-    "pmctf_conv2d_smallcin_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, vp]),
-    "pmctf_conv3x3_cin1_dual_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, vp]),
+    "pmctf_conv2d_nhwc_opts_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, ci, vp, vp]),
+    "pmctf_conv2d_nhwc_geom_opts_f32": (ci, [vp] * 6 + [ci] * 13 + [cf, ci, vp, vp]),
+    "pmctf_conv2d_smallcin_f32": (ci, [vp] * 6 + [ci] * 11 + [cf, ci, vp]),
+    "pmctf_conv3x3_cin1_dual_f32": (ci, [vp] * 5 + [ci] * 5 + [cf, ci, vp]),
     "pmctf_conv2d_fewcout_supported": (ci, [ci] * 3),
-    "pmctf_conv2d_fewcout_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
+    "pmctf_conv2d_fewcout_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, ci, vp]),
     "pmctf_fourstep_estimate_f32": (ci, [vp] * 3 + [ci] * 5 + [vp, vp]),
     "pmctf_ll_estimate_f32": (ci, [vp, vp, ci, i64, vp, vp]),
     "pmctf_z_estimate_f32": (ci, [vp, vp, vp, i64, ci, vp, vp]),
@@ -48,8 +50,8 @@ _SIGS = {
     "pmctf_conv3x3_split_pack_weights": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pmctf_conv3x3_split_f32": (ci, [vp] * 6 + [ci] * 7 + [cf, vp]),
     "pmctf_conv3x3_split_geom_f32": (ci, [vp] * 6 + [ci] * 12 + [cf, vp]),
-    "pmctf_predict_update_fused_f32": (ci, [vp] * 11 + [ci] * 4 + [cf] * 6 + [vp]),
-    "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, vp]),
+    "pmctf_predict_update_fused_f32": (ci, [vp] * 11 + [ci] * 4 + [cf] * 6 + [ci, ci, vp]),
+    "pmctf_lift_skip3_f32": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp]),
     "pmctf_nearest_up2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "pmctf_pixel_shuffle2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, vp]),
     "pmctf_ffn3_mix_f32": (ci, [vp, vp, i64, ci, vp]),

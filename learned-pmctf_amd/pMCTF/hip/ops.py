@@ -5,8 +5,10 @@ host-side weight staging; every numeric operation is a call into libpmctf_hip.so
 Feature maps are NHWC float32 tensors of shape (N, H, W, C); single-channel planes
 (N, 1, H, W) alias the same memory.
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -14,6 +16,7 @@ import torch
 from . import lib as _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+SUM_CHAIN, SUM_BLOCKS = 0, 1        # PMCTF_SUM_* of include/pmctf_hip.h: the summation rule of a convolution
 
 # Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
 # dominant kernel).  CONV_PROBE = {"match": fn(conv, x, stride) -> bool, "events": [(start, end, flops)]}
@@ -24,6 +27,31 @@ SPLIT_MIN_PX = int(os.environ.get("PMCTF_SPLIT_MIN_PX", "30000"))
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ConvLaunchOpts(C.Structure):
+    """pmctf_conv_launch_opts (include/pmctf_hip.h): launch-shape options handed over WITH a launch; < 0 = process knob"""
+    _fields_ = [("split", C.c_long), ("msplit_px", C.c_long)]
+
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def launch_opts(opts):
+    """Convolutions launched by the calling thread inside the block carry `opts` (a ConvLaunchOpts, or None) as their
+    per-launch argument.  Nothing process-wide is touched: other host threads keep their own launch shapes."""
+    prev = getattr(_tls, "opts", None)
+    _tls.opts = opts
+    try:
+        yield
+    finally:
+        _tls.opts = prev
+
+
+def _opts():
+    o = getattr(_tls, "opts", None)
+    return None if o is None else C.byref(o)
 
 
 def _p(t):
@@ -47,13 +75,16 @@ class Conv2d:
     """A packed nn.Conv2d (groups=1): weights re-laid out once for the MFMA kernel
     (Cin % 4 == 0) or kept OIHW for the small-Cin vector kernel."""
 
-    def __init__(self, weight, bias, stride=1, padding=(0, 0), device="cuda", split=0):
-        """split = 1, 2 or 3: ALSO pack bf16-split weights for the auxiliary reduced-precision kernel (conv_split.hip) and
+    def __init__(self, weight, bias, stride=1, padding=(0, 0), device="cuda", split=0, rule=SUM_CHAIN):
+        """rule: the layer's summation rule (SUM_CHAIN / SUM_BLOCKS, include/pmctf_hip.h) — part of the layer's arithmetic,
+        chosen by whoever owns the layer (HipEngine.sum_rule), never by the launch shape.
+        split = 1, 2 or 3: ALSO pack bf16-split weights for the auxiliary reduced-precision kernel (conv_split.hip) and
         use it on planes of at least SPLIT_MIN_PX output pixels when the shape is supported; 0 (default): exact f32 only."""
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.stride = int(stride)
+        self.rule = int(rule)
         self.pad = (int(padding[0]), int(padding[1])) if isinstance(padding, (tuple, list)) else (int(padding),) * 2
         self.small = self.Cin <= 4
         L = _lib.hip()
@@ -111,10 +142,11 @@ class Conv2d:
         L = _lib.hip()
         if self.few:
             _lib.check(L.pmctf_conv2d_fewcout_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
-                                                  self.Cout, self.KH, int(act), float(slope), _stream()), "conv2d_fewcout")
+                                                  self.Cout, self.KH, int(act), float(slope), self.rule, _stream()),
+                       "conv2d_fewcout")
             return y
-        fn = L.pmctf_conv2d_smallcin_f32 if self.small else L.pmctf_conv2d_nhwc_f32
-        probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](self, x, self.stride)) else None
+        probe = CONV_PROBE if (CONV_PROBE is not None and not torch.cuda.is_current_stream_capturing()
+                               and CONV_PROBE["match"](self, x, self.stride)) else None
         if probe is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -122,10 +154,14 @@ class Conv2d:
             _lib.check(L.pmctf_conv3x3_split_f32(_p(x), C.c_void_p(self.w16.data_ptr()), _p(self.b), _p(res1), _p(res2),
                                                  _p(y), N, H, W, Cin, self.Cout, self.split, int(act), float(slope),
                                                  _stream()), "conv3x3_split")
+        elif self.small:
+            _lib.check(L.pmctf_conv2d_smallcin_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
+                                                   self.Cout, self.KH, self.KW, self.stride, self.pad[0], self.pad[1],
+                                                   int(act), float(slope), self.rule, _stream()), "conv2d_smallcin")
         else:
-            _lib.check(fn(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin, self.Cout,
-                          self.KH, self.KW, self.stride, self.pad[0], self.pad[1], int(act), float(slope), _stream()),
-                       "conv2d")
+            _lib.check(L.pmctf_conv2d_nhwc_opts_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
+                                                    self.Cout, self.KH, self.KW, self.stride, self.pad[0], self.pad[1],
+                                                    int(act), float(slope), self.rule, _opts(), _stream()), "conv2d")
         if probe is not None:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))
@@ -143,7 +179,7 @@ def conv3x3_cin1_dual(conv, x, act2):
     y = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
     y2 = torch.empty_like(y)
     _lib.check(_lib.hip().pmctf_conv3x3_cin1_dual_f32(_p(x), _p(conv.w), _p(conv.b), _p(y), _p(y2), N, H, W, 16, int(act2),
-                                                      0.0, _stream()), "conv3x3_cin1_dual")
+                                                      0.0, conv.rule, _stream()), "conv3x3_cin1_dual")
     return y, y2
 
 
@@ -257,25 +293,27 @@ def spynet_pack8(im1, warped, flow_up):
     return out
 
 
-def lift_skip3(x, w3, bias):
+def lift_skip3(x, w3, bias, rule=SUM_CHAIN):
     N, Cc, H, W = x.shape
     y = torch.empty_like(x)
     _lib.check(_lib.hip().pmctf_lift_skip3_f32(_p(x), _p(y), N * Cc, H, W, float(w3[0]), float(w3[1]), float(w3[2]),
-                                               float(bias), _stream()), "lift_skip3")
+                                               float(bias), int(rule), _stream()), "lift_skip3")
     return y
 
 
-def predict_update_fused(x, other, pu, mode, c=1.0, sign=1.0, lift=(0.0, 0.0, 0.0, 0.0)):
+def predict_update_fused(x, other, pu, mode, c=1.0, sign=1.0, lift=(0.0, 0.0, 0.0, 0.0), skip_rule=SUM_CHAIN):
     """pu: (conv1, conv2, conv3, conv4) Conv2d objects of one PredictUpdate block.  mode 0: (x + PU(x)*0.1)*c;
-    mode 1: other + sign * (skip + PU(skip/256)*256*0.1) with skip = reflect 3x1 conv of x (lift = w0, w1, w2, bias)."""
+    mode 1: other + sign * (skip + PU(skip/256)*256*0.1) with skip = reflect 3x1 conv of x (lift = w0, w1, w2, bias;
+    skip_rule: summation rule of that 3x1 filter).  The four layers carry their own rule (one for the block)."""
     c1, c2, c3, c4 = pu
     N, Cc, H, W = x.shape
     assert Cc == 1 and c1.small and c4.few and not c2.small and not c2.few
+    assert c1.rule == c2.rule == c3.rule == c4.rule
     out = torch.empty_like(x)
     _lib.check(_lib.hip().pmctf_predict_update_fused_f32(
         _p(x), _p(other), _p(out), _p(c1.w), _p(c1.b), _p(c2.w), _p(c2.b), _p(c3.w), _p(c3.b), _p(c4.w), _p(c4.b),
         N, H, W, int(mode), float(c), float(sign), float(lift[0]), float(lift[1]), float(lift[2]), float(lift[3]),
-        _stream()), "predict_update_fused")
+        c1.rule, int(skip_rule), _stream()), "predict_update_fused")
     return out
 
 
@@ -333,7 +371,8 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
     assert H % 2 == 0 and W % 2 == 0 and Cin == conv.Cin
     py, px = cls >> 1, cls & 1
     y = torch.empty((N, H // 2, W // 2, conv.Cout), dtype=torch.float32, device=x.device)
-    probe = CONV_PROBE if (CONV_PROBE is not None and CONV_PROBE["match"](conv, x, 2)) else None
+    probe = CONV_PROBE if (CONV_PROBE is not None and not torch.cuda.is_current_stream_capturing()
+                           and CONV_PROBE["match"](conv, x, 2)) else None
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -343,9 +382,10 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
                                                            1 - px, H // 2, W // 2, int(act), float(slope), _stream()),
                    "conv3x3_split_geom")
     else:
-        _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H, W,
-                                                         Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2, int(act),
-                                                         float(slope), _stream()), "conv2d_geom")
+        _lib.check(_lib.hip().pmctf_conv2d_nhwc_geom_opts_f32(_p(x), _p(conv.w), _p(conv.b), _p(res1), _p(res2), _p(y), N, H,
+                                                              W, Cin, conv.Cout, 3, 3, 2, 1 - py, 1 - px, H // 2, W // 2,
+                                                              int(act), float(slope), conv.rule, _opts(), _stream()),
+                   "conv2d_geom")
     if probe is not None:
         e1.record()
         probe["events"].append((e0, e1, 2.0 * y.numel() * Cin * 9))

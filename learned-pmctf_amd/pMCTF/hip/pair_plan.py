@@ -26,11 +26,80 @@ and every two plans run one after the other) — so the scratch memory of the ~3
 chain, not once per plan: ~8 GB per engine at 1080p instead of ~60.
 """
 import os
+import threading
+import weakref
 
 import torch
 
+from . import ops
 
-_BROKEN = []
+
+class _Resources:
+    """Who destroys a launch plan's HIP objects, and when.
+
+    Destroying a HIP graph (and handing its memory pool back) while ANY stream of the process is being captured ends
+    the process, and Python decides by itself when an object dies: a model that was dropped leaves its engine and plans
+    behind as garbage, and the collector — or a worker thread letting go of the last reference — may find them at any
+    moment, including in the middle of another model's recording.  So no plan owns its graphs alone: this registry holds
+    a second reference to everything a plan (and an engine's plan context) keeps alive on the device.  When the owner
+    dies, its finaliser only moves that bundle to `retired` (pure Python, legal anywhere); `drain()` — called where no
+    capture can be open: before a recording starts (under the capture gate), when an engine is built or released —
+    synchronises the device and lets the bundles go."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.live = {}              # token -> bundle (dict / list of graphs, static tensors, pinned buffers, streams)
+        self.retired = []
+        self.recording = 0          # recordings in progress (they hold the capture gate exclusively: 0 or 1)
+        self.broken = []            # graph objects of failed captures, see _Capture.abort
+        self.next = 0
+        self.stats = {"adopted": 0, "retired": 0, "destroyed": 0, "retired_while_recording": 0}
+
+    def adopt(self, owner, bundle):
+        with self.lock:
+            token = self.next
+            self.next += 1
+            self.live[token] = bundle
+            self.stats["adopted"] += 1
+        weakref.finalize(owner, self._retire, token)
+        return token
+
+    def _retire(self, token):
+        with self.lock:
+            bundle = self.live.pop(token, None)
+            if bundle is not None:
+                self.retired.append(bundle)
+                self.stats["retired"] += 1
+                if self.recording:
+                    self.stats["retired_while_recording"] += 1
+
+    def drain(self):
+        """destroy what dead plans left behind; a no-op while a recording is in progress (the next safe point does it)"""
+        with self.lock:
+            if self.recording or not self.retired:
+                return 0
+            gone, self.retired = self.retired, []
+        if torch.cuda.is_available():
+            assert not torch.cuda.is_current_stream_capturing()
+            torch.cuda.synchronize()
+        n = len(gone)
+        del gone[:]                 # the graphs, their pools, the pinned buffers go here
+        with self.lock:
+            self.stats["destroyed"] += n
+        return n
+
+    def begin_recording(self):
+        self.drain()
+        with self.lock:
+            self.recording += 1
+
+    def end_recording(self):
+        with self.lock:
+            self.recording -= 1
+
+
+RESOURCES = _Resources()
+IN_CAPTURE_HOOK = None      # tests: called once inside an open capture of every recording (e.g. to force a collection)
 
 
 class _Capture:
@@ -40,8 +109,10 @@ class _Capture:
         self.graphs = []
         self.g = None
         self.pool = pool
+        self.stream = None
 
     def begin(self):
+        self.stream = torch.cuda.current_stream()
         self.g = torch.cuda.CUDAGraph()
         self.g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
 
@@ -55,14 +126,20 @@ class _Capture:
         self.g = None
 
     def abort(self):
+        """a recording failed: close the open capture — on the stream it was opened on, whatever the caller's current
+        stream is by now (an exception has usually unwound the `with torch.cuda.stream(...)` block already; ending the
+        capture from another stream fails and leaves the stream capturing for good) — so that the engine can go on with
+        stream launches"""
         if self.g is not None:
             try:
-                self.g.capture_end()
+                with torch.cuda.stream(self.stream):
+                    self.g.capture_end()
+                self.graphs.append(self.g)      # a valid, partial graph: destroyed like any other (RESOURCES)
             except Exception:  # noqa: BLE001 - the original error is the one to report
-                pass
-            # a graph object whose capture was invalidated throws from its destructor (which ends the process): it is
-            # kept alive for good instead
-            _BROKEN.append(self.g)
+                # a graph object whose capture was invalidated throws from its destructor (which ends the process): it
+                # is never destroyed.  Bounded: an engine whose recording failed stops recording
+                # (pMCTF.encode_one_stage), so at most one object per engine ends up here.
+                RESOURCES.broken.append(self.g)
             self.g = None
 
 
@@ -92,45 +169,32 @@ class PairPlan:
             self.host[k + "c"] = pin(n_c)
         self.segments = {}          # job name -> SymbolStream.segments of that bitstream
         # The coders of a plan run side by side: the other stream fills the tail of a launch, so the convolutions are
-        # recorded WITHOUT the whole-rounds + remainder cut that pays on a single stream (process-wide knob of the conv
-        # dispatcher; nothing else launches while a plan is recorded, see HipEngine.gate)
-        from . import lib as _lib
-        L = _lib.hip()
-        # Measured on the harness loop (tools/eager_gop.py, same box, CONV_OPTIONS): with the cut off, planes of 200 000 to
-        # 400 000 pixels (chroma's level-0 subbands, 2x288x480) are better on the barrier-free 8x32-tile kernel than on the
-        # 4x16-tile one (BIGPX_NOSPLIT, the dispatcher's default: 5.62 -> 5.67 frames/s), and splitting a launch by cout
-        # tile only pays below 40 000 pixels instead of 70 000 (5.66 -> 5.68): the other stream supplies the workgroups a
-        # lone launch lacks.
-        plan_knobs = {b"SPLIT": int(os.environ.get("PMCTF_PLAN_SPLIT", "0")),
-                      b"MSPLIT_PX": int(os.environ.get("PMCTF_PLAN_MSPLIT_PX", "40000"))}
-        saved_knobs = {k: L.pmctf_conv2d_get_option(k) for k in plan_knobs}
-        for k, v in plan_knobs.items():
-            L.pmctf_conv2d_set_option(k, v)
-        # No finaliser may run while a capture is open: the launch plans of a model that has been dropped are destroyed
-        # when the cyclic collector finds them (an engine outlives its model as unreachable garbage), and destroying HIP
-        # graphs / returning their pools inside another capture ends the process.  Collect them NOW, keep the collector
-        # off until the last graph of this plan is closed.
-        import gc
-        gc_was_on = gc.isenabled()
-        gc.collect()
+        # recorded WITHOUT the whole-rounds + remainder cut that pays on a single stream, and cut by cout tile only below
+        # 40 000 pixels instead of 70 000 (measured on the harness loop, tools/eager_gop.py: 5.62 -> 5.67 -> 5.68
+        # frames/s).  The options travel WITH every launch (ops.launch_opts -> pmctf_conv2d_nhwc_opts_f32); nothing
+        # process-wide changes, so a model on another host thread keeps its own launch shapes.
+        # The device objects of this plan are co-owned by RESOURCES (see there): whoever drops the plan, whenever, its
+        # graphs are destroyed at the next point where no capture can be open.
         torch.cuda.synchronize(dev)
-        gc.disable()
+        RESOURCES.begin_recording()
         try:
-            self._record(eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample)
+            with ops.launch_opts(eng.plan_launch_opts):
+                self._record(eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample)
         finally:
-            if gc_was_on:
-                gc.enable()
-            for k, v in saved_knobs.items():
-                L.pmctf_conv2d_set_option(k, v)
+            RESOURCES.end_recording()
+            RESOURCES.adopt(self, dict(self.__dict__))
 
     def _record(self, eng, pool_y, pool_c, dev, code_lt, stage_idx, q_index, me_downsample):
         cap = _Capture(pool_y)
+        self._captures = [cap]      # every graph of this recording, also of a failed one, is co-owned by RESOURCES
         cur = torch.cuda.current_stream(dev)
         side = eng.plan_context()["capture"]
         side.wait_stream(cur)
         try:
             with torch.cuda.stream(side):
                 cap.begin()
+                if IN_CAPTURE_HOOK is not None:
+                    IN_CAPTURE_HOOK()
                 est = eng.motion_estimate(self.in_ry, self.in_cy, me_downsample)
                 cap.cut()
                 mv = eng.motion_code(est, self.in_dpb, stage_idx, q_index, False, me_downsample)
@@ -143,6 +207,7 @@ class PairPlan:
 
                 def analysis(ref, cur_, chroma):
                     c = _Capture(pool_c if chroma else pool_y)
+                    self._captures.append(c)
                     suffix = "c" if chroma else ""
 
                     def on_stream(kind, stream):
@@ -159,6 +224,7 @@ class PairPlan:
                         c.abort()
                         raise
                     s = _Capture(pool_c if chroma else pool_y)
+                    self._captures.append(s)
                     s.begin()
                     try:
                         out["finish"]()

@@ -57,17 +57,22 @@ static void pm_parallel_for(long n, long chunk, pm_job_fn fn, void *ctx) {
  * Replaces nn.Conv2d / F.conv2d at e.g. pMCTF/layers/video/video_net.py:78-90,
  * pMCTF/layers/lifting_1d.py:30-47, pMCTF/layers/context_fusion_4step.py:12-20,
  * pMCTF/layers/postprocessing.py:9-44, pMCTF/layers/video/layers.py:22-136.
- * Order per output element:
- *   acc = bias[co]
- *   for cb in chunks of 16 input channels:
- *     for ky: for kx: for ci in chunk: acc = fmaf(x, w, acc)   (out-of-image taps skipped == +0)
+ * Two summation rules per output element:
+ *   rule 0 ("chain"):   acc = bias[co]
+ *                       for cb in chunks of 16 input channels:
+ *                         for ky: for kx: for ci in chunk: acc = fmaf(x, w, acc)   (out-of-image taps skipped == +0)
+ *                       This is also what ATen's CPU path (oneDNN jit_1x1) computes for the 1x1 layers of the path
+ *                       whose reduction is one block, and for depthwise layers.
+ *   rule 1 ("blocks"):  for every chunk cb of 16 input channels a chain FROM ZERO
+ *                         S_cb = 0; for ky: for kx: for ci in chunk: S_cb = fmaf(x, w, S_cb)
+ *                       out = (..((S_0 + bias) + S_1) + S_2 ..) + S_last
+ *                       This is what ATen's CPU path (oneDNN 3.7.1 jit:avx512_core direct convolution) computes for every
+ *                       KH*KW > 1 convolution of the path, measured bit for bit (tools/aten_conv_rules.py).
  * ------------------------------------------------------------------------- */
 #define PM_XB 32 /* output columns kept in registers */
-static int pm_conv_order = 0;
-void pm_set_conv_order(int o) { pm_conv_order = o; }
 typedef struct {
     const float *xp, *w, *bias; float *y;
-    int N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc;
+    int N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc, rule;
 } pm_conv_ctx;
 
 static void pm_conv_job(long job, void *vctx) {
@@ -83,9 +88,8 @@ static void pm_conv_job(long job, void *vctx) {
     const float b = c->bias ? c->bias[co] : 0.0f;
     for (int xb = 0; xb < Wo; xb += PM_XB) {
         float acc[PM_XB];
-        if (stride == 1 && pm_conv_order == 1 && KH * KW > 1) {
-            /* EXPERIMENT: oneDNN jit:avx512_core order — per 16-channel block a chain from zero, block sums added to
-             * the running output, bias added after the first block */
+        if (stride == 1 && c->rule == 1) {
+            /* 4 x 8 lanes held in registers; _mm256_fmadd_ps is the same single-rounding fmaf per lane */
             __m256 t0 = _mm256_setzero_ps(), t1 = t0, t2 = t0, t3 = t0;
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
                 const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
@@ -109,7 +113,7 @@ static void pm_conv_job(long job, void *vctx) {
             }
             _mm256_storeu_ps(acc, t0); _mm256_storeu_ps(acc + 8, t1);
             _mm256_storeu_ps(acc + 16, t2); _mm256_storeu_ps(acc + 24, t3);
-        } else if (pm_conv_order == 1 && KH * KW > 1) {
+        } else if (c->rule == 1) {
             float tot[PM_XB];
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
                 const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
@@ -126,7 +130,6 @@ static void pm_conv_job(long job, void *vctx) {
             }
             for (int j = 0; j < PM_XB; ++j) acc[j] = tot[j];
         } else if (stride == 1) {
-            /* 4 x 8 lanes held in registers; _mm256_fmadd_ps is the same single-rounding fmaf per lane */
             __m256 a0 = _mm256_set1_ps(b), a1 = a0, a2 = a0, a3 = a0;
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
                 const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
@@ -162,9 +165,9 @@ static void pm_conv_job(long job, void *vctx) {
     }
 }
 
-void pm_conv2d(const float *restrict x, const float *restrict w, const float *restrict bias, float *restrict y,
-               int N, int Cin, int H, int W, int Cout, int KH, int KW,
-               int stride, int pad_h, int pad_w) {
+void pm_conv2d_rule(const float *restrict x, const float *restrict w, const float *restrict bias, float *restrict y,
+                    int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                    int stride, int pad_h, int pad_w, int rule) {
     const int Ho = (H + 2 * pad_h - KH) / stride + 1;
     const int Wo = (W + 2 * pad_w - KW) / stride + 1;
     /* zero-padded copy of the input: out-of-image taps then contribute fmaf(0, w, acc) == acc,
@@ -181,9 +184,15 @@ void pm_conv2d(const float *restrict x, const float *restrict w, const float *re
         const long n = nc / Cin; const int ci = (int)(nc % Cin);
         memcpy(xp + ((n * Hc + iy + pad_h) * Cin + ci) * Wc + pad_w, x + r * W, (size_t)W * sizeof(float));
     }
-    pm_conv_ctx c = {xp, w, bias, y, N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc};
+    pm_conv_ctx c = {xp, w, bias, y, N, Cin, Cout, KH, KW, stride, Ho, Wo, Hc, Wc, rule};
     pm_parallel_for((long)N * Cout * Ho, Cout < 16 ? Cout : 16, pm_conv_job, &c);
     free(xp);
+}
+
+void pm_conv2d(const float *restrict x, const float *restrict w, const float *restrict bias, float *restrict y,
+               int N, int Cin, int H, int W, int Cout, int KH, int KW,
+               int stride, int pad_h, int pad_w) {
+    pm_conv2d_rule(x, w, bias, y, N, Cin, H, W, Cout, KH, KW, stride, pad_h, pad_w, 0);
 }
 
 /* depthwise KxK conv, stride 1, zero pad K/2 (pMCTF/layers/video/layers.py:117-118).

@@ -33,6 +33,7 @@ def lib():
         build()
     L = C.CDLL(_SO)
     L.pm_conv2d.argtypes = [f32p, f32p, C.c_void_p, f32p] + [C.c_int] * 10
+    L.pm_conv2d_rule.argtypes = [f32p, f32p, C.c_void_p, f32p] + [C.c_int] * 11
     L.pm_dwconv2d.argtypes = [f32p, f32p, C.c_void_p, f32p] + [C.c_int] * 5
     for n in ("pm_tanh_arr", "pm_sigmoid_arr", "pm_log_arr", "pm_exp_arr"):
         getattr(L, n).argtypes = [f32p, f32p, C.c_long]
@@ -79,7 +80,7 @@ def _c(a, dt=np.float32):
     return np.ascontiguousarray(a, dtype=dt)
 
 
-def conv2d(x, w, b, stride=1, pad=(0, 0)):
+def conv2d(x, w, b, stride=1, pad=(0, 0), rule=0):
     x, w = _c(x), _c(w)
     N, Cin, H, W = x.shape
     Cout, Cin2, KH, KW = w.shape
@@ -92,7 +93,7 @@ def conv2d(x, w, b, stride=1, pad=(0, 0)):
     if b is not None:
         b = _c(b)
         bp = b.ctypes.data
-    lib().pm_conv2d(x, w, bp, y, N, Cin, H, W, Cout, KH, KW, stride, ph, pw)
+    lib().pm_conv2d_rule(x, w, bp, y, N, Cin, H, W, Cout, KH, KW, stride, ph, pw, rule)
     return y
 
 

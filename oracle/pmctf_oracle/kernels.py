@@ -95,14 +95,14 @@ class TorchK:
 class CdefK(TorchK):
     name = "cdef"
 
-    def conv2d(self, x, w, b, stride=1, padding=0, groups=1):
+    def conv2d(self, x, w, b, stride=1, padding=0, groups=1, rule=0):
         pad = padding if isinstance(padding, (tuple, list)) else (padding, padding)
         stride = stride[0] if isinstance(stride, (tuple, list)) else stride
         xn = x.detach().numpy()
         wn = w.detach().numpy()
         bn = None if b is None else b.detach().numpy()
         if groups == 1:
-            return _t(clib.conv2d(xn, wn, bn, stride, pad))
+            return _t(clib.conv2d(xn, wn, bn, stride, pad, rule))
         assert groups == x.size(1) == w.size(0) and w.size(1) == 1 and stride == 1 and pad[0] == w.size(2) // 2
         return _t(clib.dwconv2d(xn, wn, bn))
 

@@ -78,9 +78,31 @@ class Oracle:
         if self.tap_enabled:
             self.taps[name] = t.detach().clone()
 
+    SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
+
+    @classmethod
+    def sum_rule(cls, p, x, w, groups=1):
+        """Summation rule of the PM-F32 back-end for the convolution with parameter key p (oracle/c/pm_ops.c: 0 = one chain
+        from the bias, 1 = per-16-channel-block sums from zero added in turn, bias after the first block).  KH*KW > 1
+        layers of the signal path (motion estimation, motion codec, temporal and spatial lifting) follow rule 1, which is
+        what ATen's CPU path computes for them (measured: tools/aten_conv_rules.py); everything else rule 0.  One
+        shape-dependent exception, also ATen's: a lifting step's 3x1 filter whose (reflect-padded) input is ONE plane of
+        at most 20 480 elements does not go through oneDNN (Convolution.cpp `use_mkldnn`) but through im2col + gemv,
+        which starts from the bias — rule 0."""
+        if groups != 1 or w.size(2) * w.size(3) == 1:
+            return 0
+        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+            return 0
+        if w.size(0) == 1 and w.size(1) == 1 and w.size(3) == 1 and x.size(0) == 1 and x.numel() <= 20480:
+            return 0
+        return 1
+
     def conv(self, p, x, stride=1, padding=0, groups=1):
-        return self.K.conv2d(x, self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride=stride, padding=padding,
-                             groups=groups)
+        w = self.sd[p + ".weight"]
+        if self.K.name == "cdef":
+            return self.K.conv2d(x, w, self.sd.get(p + ".bias"), stride=stride, padding=padding, groups=groups,
+                                 rule=self.sum_rule(p, x, w, groups))
+        return self.K.conv2d(x, w, self.sd.get(p + ".bias"), stride=stride, padding=padding, groups=groups)
 
     # ------------------------------------------------------------------ a6: PredictUpdate, lifting_1d.py:36-49
     def predict_update(self, p, x):

@@ -849,6 +849,99 @@ def test_pair_plan_equals_stream_launches(cuda):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_dropped_model_never_destroys_graphs_inside_another_recording(cuda):
+    """The failure behind last round's intermittent abort, as a deterministic sequence: model A records launch plans and
+    is dropped WITHOUT release() while its engine sits in a reference cycle (so nothing dies by reference count); model
+    B then records its first plan and a full collection is forced INSIDE B's open capture — exactly when the collector
+    used to find A's engine and destroy its HIP graphs, which ends the process.  Now the plans' device objects are
+    co-owned by pair_plan.RESOURCES: the collection only retires them (counted), nothing is destroyed while the capture
+    is open, B's plan records and replays with the stream path's bits, and the graphs go at the next safe point.  A
+    second thread dropping the last reference to a plan during a recording takes the same route.  Recording also leaves
+    the process-wide dispatcher knobs and the cyclic collector alone."""
+    import gc
+    import threading
+    import pmctf_gop
+    from pMCTF.hip import lib as hiplib
+    from pMCTF.hip import pair_plan
+    R = pair_plan.RESOURCES
+    L = hiplib.hip()
+    knobs = {k: L.pmctf_conv2d_get_option(k) for k in (b"SPLIT", b"MSPLIT_PX")}
+    fr = frames(W, H, 4, device="cuda", seed=41)
+
+    def gop(net):
+        with tempfile.TemporaryDirectory() as td:
+            enc = pmctf_gop.encode_gop(net, fr, H, W, 3, td)
+            return enc["bits"], {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+
+    gc.collect()
+    R.drain()
+    net_a, _ = product_model(1)
+    bits_a, files_a = gop(net_a)                    # pairs 2 and 3 record plans ("later pair of the chain", "with L")
+    eng_a = net_a.engine()
+    n_plans = len(eng_a.pair_plans)
+    assert n_plans >= 2
+    spare = next(iter(eng_a.pair_plans.values()))   # one plan whose LAST reference a worker thread will drop
+    eng_a.cycle = eng_a                             # the engine is garbage only the cyclic collector finds
+    net_a._engine = None                            # ... and the model's finaliser cannot release it
+    gc.disable()                                    # (the TEST holds the collector back so that it strikes inside the capture)
+    del net_a, eng_a
+    before = dict(R.stats)
+    events = []
+
+    def in_capture():
+        pair_plan.IN_CAPTURE_HOOK = None            # the first recording only
+        assert torch.cuda.is_current_stream_capturing()
+        destroyed = R.stats["destroyed"]
+        gc.collect()                                # finds A's engine: its plans retire, their graphs stay alive
+        box = [spare_holder.pop()]
+        t = threading.Thread(target=box.clear)      # another thread lets go of the last reference to a plan
+        t.start()
+        t.join()
+        assert R.drain() == 0                       # a drain attempt inside a recording is a no-op
+        events.append((R.stats["retired_while_recording"], R.stats["destroyed"] - destroyed, len(R.retired)))
+    spare_holder = [spare]
+    del spare
+    pair_plan.IN_CAPTURE_HOOK = in_capture
+    try:
+        net_b, _ = product_model(1)
+        bits_b, files_b = gop(net_b)
+    finally:
+        pair_plan.IN_CAPTURE_HOOK = None
+        gc.enable()
+    assert events, "model B recorded no plan"
+    retired_in_capture, destroyed_in_capture, parked = events[0]
+    assert retired_in_capture - before["retired_while_recording"] >= n_plans and destroyed_in_capture == 0 and parked >= n_plans
+    assert bits_b == bits_a and files_b == files_a
+    assert net_b.engine().use_graphs and len(net_b.engine().pair_plans) >= 2        # no recording failed
+    assert gc.isenabled()
+    assert {k: L.pmctf_conv2d_get_option(k) for k in knobs} == knobs
+    bits_c, files_c = gop(net_b)                    # replays B's plans
+    assert bits_c == bits_a and files_c == files_a
+    net_b._drop_engine()                            # a safe point: everything retired so far is destroyed
+    gc.collect()
+    R.drain()
+    assert not R.retired and R.stats["destroyed"] - before["destroyed"] >= n_plans
+    assert len(R.broken) == 0
+
+    # a recording that FAILS half-way (here: an exception inside the open capture) must leave no stream capturing: the
+    # engine warns, goes on with stream launches and produces the same files
+    def boom():
+        pair_plan.IN_CAPTURE_HOOK = None
+        raise RuntimeError("injected failure inside an open capture")
+    pair_plan.IN_CAPTURE_HOOK = boom
+    try:
+        net_c, _ = product_model(1)
+        with pytest.warns(UserWarning, match="recording the launch plan failed"):
+            bits_d, files_d = gop(net_c)
+    finally:
+        pair_plan.IN_CAPTURE_HOOK = None
+    torch.cuda.synchronize()                        # would raise "operation not permitted when stream is capturing"
+    assert not net_c.engine().use_graphs and bits_d == bits_a and files_d == files_a
+    net_c._drop_engine()
+    R.drain()
+    assert not R.retired
+
+
 @pytest.mark.parametrize("gop", [16, 8])
 def test_headline_config_stage_batched_vs_reference(cuda, gop):
     """The stage-batched schedule (pairs of a temporal stage as one batch; bench.py's auxiliary figure) on the headline

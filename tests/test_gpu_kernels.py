@@ -66,8 +66,10 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("rule", [0, 1], ids=["chain", "blocks"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
-def test_conv2d_bitexact(cuda, case):
+def test_conv2d_bitexact(cuda, case, rule):
+    """every layer shape of the path, under both summation rules (include/pmctf_hip.h PMCTF_SUM_*)"""
     from pmctf_oracle import clib
     from pMCTF.hip import ops
     N, Cin, H, W, Cout, K, S, P, act, slope, nres = case
@@ -75,7 +77,7 @@ def test_conv2d_bitexact(cuda, case):
     x = r.standard_normal((N, Cin, H, W), dtype=np.float32) * 3
     w = (r.standard_normal((Cout, Cin, K, K), dtype=np.float32) * 0.05).astype(np.float32)
     b = r.standard_normal(Cout, dtype=np.float32)
-    ref = clib.conv2d(x, w, b, S, (P, P))
+    ref = clib.conv2d(x, w, b, S, (P, P), rule)
     if act == 1:
         ref = np.maximum(ref, 0)
     elif act == 2:
@@ -85,7 +87,7 @@ def test_conv2d_bitexact(cuda, case):
     res = [r.standard_normal(ref.shape, dtype=np.float32) for _ in range(nres)]
     for q in res:
         ref = ref + q
-    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (P, P))
+    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (P, P), rule=rule)
     y = conv(nhwc(x), act=act, slope=slope, res1=nhwc(res[0]) if nres > 0 else None,
              res2=nhwc(res[1]) if nres > 1 else None)
     torch.cuda.synchronize()
@@ -113,10 +115,12 @@ def _random_conv_cases(seed, count):
     return cases
 
 
+@pytest.mark.parametrize("rule", [0, 1], ids=["chain", "blocks"])
 @pytest.mark.parametrize("seed", [101, 202, 303])
-def test_conv2d_random_shapes_bitexact(cuda, seed):
-    """Fuzz of pmctf_conv2d_nhwc_f32 / _smallcin_f32 / _fewcout_f32 behind ops.Conv2d against the oracle's C convolution:
-    whatever kernel variant the dispatcher picks for a shape, the bits are PM-F32's."""
+def test_conv2d_random_shapes_bitexact(cuda, seed, rule):
+    """Fuzz of pmctf_conv2d_nhwc_opts_f32 / _smallcin_f32 / _fewcout_f32 behind ops.Conv2d against the oracle's C
+    convolution, under both summation rules (PMCTF_SUM_CHAIN / PMCTF_SUM_BLOCKS): whatever kernel variant the dispatcher
+    picks for a shape, the bits are PM-F32's for that rule."""
     from pmctf_oracle import clib
     from pMCTF.hip import ops
     for case in _random_conv_cases(seed, 24):
@@ -125,7 +129,7 @@ def test_conv2d_random_shapes_bitexact(cuda, seed):
         x = r.standard_normal((n, cin, h, w_), dtype=np.float32) * 2
         wt = (r.standard_normal((cout, cin, k, k), dtype=np.float32) * 0.1).astype(np.float32)
         b = r.standard_normal(cout, dtype=np.float32)
-        ref = clib.conv2d(x, wt, b, s, (ph, pw))
+        ref = clib.conv2d(x, wt, b, s, (ph, pw), rule)
         if act == 1:
             ref = np.maximum(ref, 0)
         elif act == 2:
@@ -137,7 +141,7 @@ def test_conv2d_random_shapes_bitexact(cuda, seed):
         res = [r.standard_normal(ref.shape, dtype=np.float32) for _ in range(nres)]
         for q in res:
             ref = ref + q
-        conv = ops.Conv2d(torch.from_numpy(wt), torch.from_numpy(b), s, (ph, pw))
+        conv = ops.Conv2d(torch.from_numpy(wt), torch.from_numpy(b), s, (ph, pw), rule=rule)
         y = conv(nhwc(x), act=act, slope=slope, res1=nhwc(res[0]) if nres > 0 else None,
                  res2=nhwc(res[1]) if nres > 1 else None)
         torch.cuda.synchronize()
@@ -211,9 +215,10 @@ def test_resample_bitexact(cuda):
                                    (1, 16, 140, 150, 16, 3, 1),
                                    (1, 32, 48, 80, 64, 7, 1), (1, 64, 45, 70, 32, 7, 1), (2, 32, 37, 50, 16, 7, 1),
                                    (1, 64, 64, 96, 128, 3, 2), (1, 192, 20, 36, 256, 1, 1)])
-def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
+@pytest.mark.parametrize("rule", [0, 1], ids=["chain", "blocks"])
+def test_conv2d_launch_shapes_do_not_change_results(cuda, shape, rule):
     """Every way of cutting a convolution into workgroups (cout-tile split, row split, tile size, kernel variant)
-    gives the same bits: pmctf_conv2d_set_option only moves work around."""
+    gives the same bits, under either summation rule: pmctf_conv2d_set_option only moves work around."""
     from pmctf_oracle import clib
     from pMCTF.hip import lib, ops
     N, Cin, H, W, Cout, K, S = shape
@@ -221,8 +226,8 @@ def test_conv2d_launch_shapes_do_not_change_results(cuda, shape):
     x = r.standard_normal((N, Cin, H, W), dtype=np.float32)
     w = (r.standard_normal((Cout, Cin, K, K), dtype=np.float32) * 0.05).astype(np.float32)
     b = r.standard_normal(Cout, dtype=np.float32)
-    ref = clib.conv2d(x, w, b, S, (K // 2, K // 2))
-    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2))
+    ref = clib.conv2d(x, w, b, S, (K // 2, K // 2), rule)
+    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), S, (K // 2, K // 2), rule=rule)
     xd = nhwc(x)
     L = lib.hip()
     defaults = {"WAVE": 1, "NT": 0, "MSPLIT_PX": 70000, "SPLIT": 1, "BIGPX": 131072, "V1": 0, "V2": 0, "RES": 0, "MSPLIT_NT": 1,
@@ -259,12 +264,13 @@ def test_conv3x3_cin1_dual_output(cuda):
     x = r.standard_normal((2, 1, 37, 70), dtype=np.float32) * 40
     w = (r.standard_normal((16, 1, 3, 3), dtype=np.float32) * 0.1).astype(np.float32)
     b = r.standard_normal(16, dtype=np.float32)
-    ref = clib.conv2d(x, w, b, 1, (1, 1))
-    conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), 1, (1, 1))
-    y, y2 = ops.conv3x3_cin1_dual(conv, nhwc(x), ops.ACT_TANH)
-    torch.cuda.synchronize()
-    assert_same(nchw(y), ref, "conv1")
-    assert_same(nchw(y2), clib.tanh(ref), "tanh(conv1)")
+    for rule in (0, 1):
+        ref = clib.conv2d(x, w, b, 1, (1, 1), rule)
+        conv = ops.Conv2d(torch.from_numpy(w), torch.from_numpy(b), 1, (1, 1), rule=rule)
+        y, y2 = ops.conv3x3_cin1_dual(conv, nhwc(x), ops.ACT_TANH)
+        torch.cuda.synchronize()
+        assert_same(nchw(y), ref, f"conv1 rule {rule}")
+        assert_same(nchw(y2), clib.tanh(ref), f"tanh(conv1) rule {rule}")
 
 
 @pytest.mark.parametrize("shape", [(1, 112, 112, 37, 53), (2, 64, 64, 48, 64), (1, 64, 112, 16, 32), (3, 112, 64, 7, 90)])

@@ -22,11 +22,25 @@ def match(conv, x, stride):
 pairs = os.environ.get("CENSUS_SCHEDULE") == "pairs"
 net.engine().use_graphs = False
 run = (lambda: pmctf_gop.encode_gop(net, frames, H, W, 3, tmp)) if pairs else (lambda: pmctf_gop.encode_gop_batched(net, frames, H, W, 3, tmp))
+import gc, time
+gc_log = []                                 # (start, seconds, generation) of every collection during the probed run
+def _gc_cb(phase, info, _t=[0.0]):
+    if phase == "start":
+        _t[0] = time.perf_counter()
+    else:
+        gc_log.append((_t[0], time.perf_counter() - _t[0], info["generation"]))
+host_t = []                                 # host clock when each probed convolution was matched (just before its launch)
+_match = match
+def match(conv, x, stride):
+    host_t.append(time.perf_counter())
+    return _match(conv, x, stride)
 with torch.no_grad():
     run(); torch.cuda.synchronize()
     probe = {"match": match, "events": []}
     ops.CONV_PROBE = probe
+    gc.callbacks.append(_gc_cb)
     run(); torch.cuda.synchronize()
+    gc.callbacks.remove(_gc_cb)
     ops.CONV_PROBE = None
 agg = collections.OrderedDict()
 for s, (e0, e1, fl) in zip(sigs, probe["events"]):
@@ -36,11 +50,27 @@ print(f"total conv ms {tot:.1f}  total TFLOP {sum(a[2] for a in agg.values())/1e
 for s, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     (N, h, w, ci), co, k, st = s
     print(f"{N}x{h}x{w} {ci:4d}->{co:4d} k{k} s{st}  n={a[0]:5d} {a[1]:8.1f} ms ({a[1]/tot*100:4.1f}%) {a[1]/a[0]*1e3:8.1f} us  {a[2]/a[1]/1e9:6.1f} TF/s")
-if len(sys.argv) > 1:                       # per-launch durations of one signature, in launch order: N H W Cin Cout
+if len(sys.argv) > 1:                       # per-launch durations of one signature, in launch order: N H W Cin Cout [K [S]]
     want = tuple(int(v) for v in sys.argv[1:5])
-    d = [round(e0.elapsed_time(e1) * 1e3) for s, (e0, e1, fl) in zip(sigs, probe["events"])
-         if s[0] == want and s[1] == int(sys.argv[5]) and s[2] == 3 and s[3] == 1]
-    print("per-launch us:", d)
+    kk = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+    ss = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    hits = [(i, round(e0.elapsed_time(e1) * 1e3)) for i, (s, (e0, e1, fl)) in enumerate(zip(sigs, probe["events"]))
+            if s[0] == want and s[1] == int(sys.argv[5]) and s[2] == kk and s[3] == ss]
+    print("per-launch us:", [d for _, d in hits])
+    med = sorted(d for _, d in hits)[len(hits) // 2]
+    print(f"median {med} us; launches above 4x the median, with the convolution probed just before them and the gap between "
+          f"that one's end and this one's start (GPU idle or other kernels):")
+    for i, d in hits:
+        if d > 4 * med and i > 0:
+            (pn, ph, pw, pci), pco, pk, pst = sigs[i - 1]
+            gap = probe["events"][i - 1][1].elapsed_time(probe["events"][i][0]) * 1e3
+            print(f"  launch #{i}: {d} us; before it {pn}x{ph}x{pw} {pci}->{pco} k{pk} s{pst}, gap {gap:.0f} us")
+            t0, t1 = host_t[i], host_t[i + 1] if i + 1 < len(host_t) else float("inf")
+            print(f"    host: {1e3 * (t1 - t0):.1f} ms between this launch and the next probed one; collections of Python's "
+                  f"cyclic GC inside that window: "
+                  f"{[(f'gen{g}', f'{1e3 * dt:.1f} ms') for ts, dt, g in gc_log if t0 <= ts <= t1] or 'none'}")
+    big = sorted(gc_log, key=lambda r: -r[1])[:5]
+    print("longest collections of the probed run:", [(f"gen{g}", f"{1e3 * dt:.1f} ms") for _, dt, g in big])
 if os.environ.get("CENSUS_SMALL"):
     print("--- planes of at most 70 000 output pixels, by time ---")
     small = [(s, a) for s, a in agg.items() if s[0][0] * (s[0][1] // s[3]) * (s[0][2] // s[3]) <= 70000]

@@ -35,7 +35,7 @@ from pmctf_oracle.kernels import CdefK, TorchK  # noqa: E402
 from pmctf_oracle.model import Oracle  # noqa: E402
 
 KINDS = ("mv", "H", "Hc", "L", "Lc")
-GROUPS = ("spynet", "mv_codec", "pu_temporal", "dwt", "ll_net", "lstm", "fs_first", "fs_heads", "fs_3x3_lvl3",
+GROUPS = ("spynet", "mv_enc", "mv_dec", "pu_temporal", "dwt_skip", "dwt_pu_c1", "dwt_pu_c23", "dwt_pu_c4", "ll_net", "lstm", "fs_first", "fs_heads", "fs_3x3_lvl3",
           "fs_3x3_lvl2", "fs_3x3_lvl1", "fs_3x3_lvl0", "post", "tanh_pu", "act_lstm", "log_index")
 
 
@@ -46,9 +46,13 @@ def group_of(key):
     if key.startswith("temporal_filtering."):
         return "pu_temporal"
     if key.startswith("mv_"):
-        return "mv_codec"
+        # what only decides the motion SYMBOLS (analysis side) / what the decoder also runs and mv_hat comes out of
+        return "mv_enc" if key.startswith(("mv_encoder.", "mv_hyper_prior_encoder.")) else "mv_dec"
     if ".wavelet_transform." in key:
-        return "dwt"
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf.startswith("conv_"):
+            return "dwt_skip"                       # the learned 3x1 filter of a lifting step
+        return {"conv1": "dwt_pu_c1", "conv2": "dwt_pu_c23", "conv3": "dwt_pu_c23", "conv4": "dwt_pu_c4"}[leaf]
     if ".context_prediction." in key:
         return "lstm"
     if ".dequantModule." in key:
@@ -101,9 +105,11 @@ class MixedOracle(Oracle):
         return group in self.pm_groups
 
     def conv(self, p, x, stride=1, padding=0, groups=1):
-        K = self.K.c if self.pm(group_of(p)) else self.K.t
-        return K.conv2d(x.contiguous(), self.sd[p + ".weight"], self.sd.get(p + ".bias"), stride=stride,
-                        padding=padding, groups=groups)
+        w, b = self.sd[p + ".weight"], self.sd.get(p + ".bias")
+        if self.pm(group_of(p)):        # PM-F32 with the summation rule the product gives this layer (Oracle.sum_rule)
+            return self.K.c.conv2d(x.contiguous(), w, b, stride=stride, padding=padding, groups=groups,
+                                   rule=self.sum_rule(p, x, w, groups))
+        return self.K.t.conv2d(x.contiguous(), w, b, stride=stride, padding=padding, groups=groups)
 
     def predict_update(self, p, x):
         self.where = "pu"

@@ -77,15 +77,9 @@ def main():
     ap.add_argument("--size", nargs="+", default=["128x128", "448x256"])
     ap.add_argument("--q", nargs="+", type=int, default=[0, 3, 4, 8, 12, 16, 20])
     ap.add_argument("--gop", type=int, default=4)
-    ap.add_argument("--conv_order", type=int, default=0,
-                    help="experiment: 1 = give the PM-F32 back-end oneDNN's summation order for k > 1 convolutions "
-                         "(per 16-channel block a chain from zero, block sums added, bias after the first block)")
     args = ap.parse_args()
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     sd = synth_sd_cpu(1)
-    if args.conv_order:
-        from pmctf_oracle import clib
-        clib.lib().pm_set_conv_order(args.conv_order)
     print("| size | q_index | symbols | symbols flipped / M | CDF rows flipped / M | first differing stream | files with "
           "different bytes | per-frame bit deltas (PM-F32 - ATen) |")
     print("|---|---|---|---|---|---|---|---|")
