@@ -36,7 +36,12 @@ extern "C" {
  *                     ATen's CPU path (oneDNN direct convolution) computes for every KH*KW > 1 layer, measured bit for bit
  *                     (tools/aten_conv_rules.py).  The drop-in path uses it for every KH*KW > 1 layer with at most 16 input
  *                     channels and for the multi-block layers of the signal path (motion estimation, motion codec, temporal
- *                     and spatial lifting): the layers whose last bits decide symbols (profiles/round4_flip_attribution.md). */
+ *                     and spatial lifting): the layers whose last bits decide symbols (profiles/round4_flip_attribution.md).
+ *   B >= 16, B % 16 == 0 ("reduce-B", entry points with an MFMA path only): blocks of B input channels; the FIRST block's
+ *                     chain starts at the bias, later blocks at zero, block results added in turn (B >= Cin is the chain).
+ *                     What ATen's jit_1x1 kernel computes for the 1x1 layers whose reduction it blocks; B follows from the
+ *                     layer's shape (pMCTF/hip/aten_rules.py, e.g. 256 -> 64 on a 576x960 plane: B = 96).
+ */
 #define PMCTF_SUM_CHAIN 0
 #define PMCTF_SUM_BLOCKS 1
 

@@ -42,7 +42,11 @@ struct ConvArgs {
     // mtp: cout tiles per packed M-block (the weight layout); a workgroup handles MT <= mtp of them, blockIdx.z
     // enumerates groups of MT tiles.  [oy_base, oy_end): output rows this launch covers.
     int mtp, oy_base, oy_end;
-    int bsum;       // summation rule: 0 chain from the bias, 1 per-chunk sums from zero added in turn (see the header)
+    // summation rule (see the header): bsum 0 = one chain from the bias; bsum 1 = the reduction is cut into blocks of
+    // `bchunks` 16-channel chunks whose sums are added in turn — bias_first 0: every block's chain starts at zero and the
+    // bias is added to the first block's sum (ATen's KH*KW > 1 layers, bchunks = 1); bias_first 1: the first block's chain
+    // starts at the bias, later blocks at zero (ATen's 1x1 layers with a blocked reduction, bchunks = block / 16)
+    int bsum, bchunks, bias_first;
 };
 
 // MT: cout tiles per workgroup, NT: pixel tiles per wave, TW16: 16-pixel segments per tile row.
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = BSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = (BSUM && !a.bias_first) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
         }
@@ -128,15 +132,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 }
             }
         }
-        if constexpr (BSUM) {       // S_cb is complete: (S_0 + bias), then + S_1, + S_2 ...
-            const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+        if constexpr (BSUM) {
+            if ((cb + 1) % a.bchunks == 0 || cb + 1 == a.ncb) {     // a block's sum is complete (wave-uniform)
+                const bool first = cb < a.bchunks;
+                const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 b = *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    tot[mt][nt] = cb == 0 ? acc[mt][nt] + b : tot[mt][nt] + acc[mt][nt];
-                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < NT; ++nt) {
+                        tot[mt][nt] = first ? (a.bias_first ? acc[mt][nt] : acc[mt][nt] + b) : tot[mt][nt] + acc[mt][nt];
+                        acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }
@@ -1525,8 +1532,8 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         // the specialised 3x3 / wave-private kernels carry rule 0 only (their layers of the path that need rule 1 have at
         // most 64 couts and are a few per cent of the work)
         if constexpr (((NT == 4 && TW16 == 2) || (NT == 1 && TW16 == 1)) && MT <= 4) {
-            if (a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 && knob("K77") != 0 &&
-                (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+            if (a.bchunks == 1 && !a.bias_first && a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 &&
+                knob("K77") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
                 static std::once_flag once_7b;
                 allow_big_lds(conv7x7s1_pipe_kernel<MT, NT, true>, once_7b);
                 CONV_LAUNCH((conv7x7s1_pipe_kernel<MT, NT, true>), grid, dim3(256), 2 * smem, st, b);
@@ -1841,7 +1848,7 @@ extern "C" int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *wp, 
                                                void *stream) {
     if (!x || !wp || !bp || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0 || Ho <= 0 || Wo <= 0 ||
-        (sum_rule != PMCTF_SUM_CHAIN && sum_rule != PMCTF_SUM_BLOCKS))
+        (sum_rule != PMCTF_SUM_CHAIN && sum_rule != PMCTF_SUM_BLOCKS && (sum_rule < 16 || (sum_rule & 15))))
         return PMCTF_EINVAL;
     ConvArgs a;
     a.x = x; a.wp = wp; a.bp = bp; a.res1 = res1; a.res2 = res2; a.y = y;
@@ -1853,7 +1860,9 @@ extern "C" int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *wp, 
     a.act = act; a.slope = slope;
     a.tiles_x = a.tiles_y = 0;
     a.mtp = 1; a.oy_base = 0; a.oy_end = Ho;
-    a.bsum = sum_rule == PMCTF_SUM_BLOCKS ? 1 : 0;
+    a.bsum = 0; a.bchunks = 1; a.bias_first = 0;
+    if (sum_rule == PMCTF_SUM_BLOCKS) a.bsum = 1;
+    else if (sum_rule >= 16 && sum_rule < Cin) { a.bsum = 1; a.bchunks = sum_rule / CB; a.bias_first = 1; }   // >= Cin: one block = the chain
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;

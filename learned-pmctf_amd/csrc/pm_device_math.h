@@ -6,6 +6,7 @@
 //  pMCTF/entropy_models/entropy_models.py:271).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "pm_tanh_tables.h"
 
 namespace pm {
 
@@ -37,19 +38,35 @@ __device__ __forceinline__ float expf_(float x) {
     return (q + 1.0f) * s;
 }
 
+// tanh: the schedule of Intel MKL's vmsTanh (high accuracy, AVX-512 kernel) = torch.tanh on a float32 CPU tensor, bit for
+// bit (oracle/c/pm_math.h pm_tanhf has the derivation; tools/mkl_tanh_tables.py --verify checks it on all 2^32 inputs).
+// 32 intervals of |x|, 12 words per interval = three 16-byte loads from a 1.5 KB table that lives in L1 / the scalar cache.
+struct __attribute__((aligned(16))) TanhRow { unsigned w[12]; };
+static __device__ const TanhRow tanh_rows[32] = PM_TANH_TABLE_BY_INTERVAL;
+
 __device__ __forceinline__ float tanhf_(float x) {
-    const float a = __builtin_fabsf(x);
-    int n;
-    const float q = exp_core(-2.0f * a, n);
-    float em1;
-    if (n == 0) {
-        em1 = q;
-    } else {
-        const float s = u2f((unsigned)(n + 127) << 23);
-        em1 = (q + 1.0f) * s - 1.0f;
+    const unsigned ux = f2u(x);
+    const unsigned ix = ux & PM_TANH_EXPMASK;
+    int t = (int)(ix - PM_TANH_BIAS);
+    t = t < 0 ? 0 : t;
+    t = t > (int)PM_TANH_IDXMAX ? (int)PM_TANH_IDXMAX : t;
+    const uint4 *row = (const uint4 *)tanh_rows[t >> 21].w;
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2];        // B T_hi T_lo C1 | C3 C4 C5 C6 | C7 - - -
+    const float y = u2f(ux & PM_TANH_ABS) - u2f(r0.x);
+    float p = u2f(r2.x);
+    p = __builtin_fmaf(p, y, u2f(r1.w));
+    p = __builtin_fmaf(p, y, u2f(r1.z));
+    p = __builtin_fmaf(p, y, u2f(r1.y));
+    p = __builtin_fmaf(p, y, u2f(r1.x));
+    p = p * y;
+    p = __builtin_fmaf(p, y, u2f(r0.z));
+    p = __builtin_fmaf(u2f(r0.w), y, p);
+    float r = u2f(f2u(p + u2f(r0.y)) | (ux & PM_TANH_SIGN));
+    if ((int)ix > (int)PM_TANH_BIG) {                         // |x| >= 2^127 * 1.25, infinities, NaN
+        const bool nan = (ux & 0x7f800000u) == 0x7f800000u && (ux & 0x007fffffu);
+        r = nan ? x + x : u2f((ux & PM_TANH_SIGN) | 0x3f800000u);
     }
-    const float t = -em1 / (em1 + 2.0f);
-    return __builtin_copysignf(t, x);
+    return r;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf_(-x)); }

@@ -21,6 +21,7 @@ import os
 import numpy as np
 import torch
 
+from . import aten_rules
 from . import lib as _lib
 from . import ops
 from .ops import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, EW_ADD, EW_ADD_MULS2, EW_ADD_MULS_MULS, EW_CLAMP_MULS,
@@ -325,17 +326,24 @@ class HipEngine:
     SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
 
     @classmethod
-    def sum_rule(cls, p, weight):
+    def sum_rule(cls, p, weight, stride=1):
         """Summation rule of the convolution with parameter key p (include/pmctf_hip.h PMCTF_SUM_*).
         KH*KW > 1 layers of the SIGNAL path — motion estimation, motion codec, temporal lifting, the spatial lifting DWT
         and its inverse: everything a coefficient value or the motion field is computed by — add their products the way
         ATen's CPU convolution does (per 16-channel block from zero, block sums in turn, bias after the first): measured,
         the last bits of exactly these layers decide the symbols that differed from the reference's
         (profiles/round4_flip_attribution.md).  The entropy-parameter networks, post-processing, every 1x1 and depthwise
-        layer keep the single chain from the bias (which for 1x1 / depthwise IS ATen's order)."""
-        kh, kw = int(weight.shape[2]), int(weight.shape[3])
-        if kh * kw > 1 and (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+        layer of those networks keep the single chain from the bias; so do the depthwise and the 1x1 layers of the signal
+        path, for which the chain IS ATen's order — except where ATen blocks a 1x1 layer's reduction (aten_rules)."""
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+            return ops.SUM_CHAIN
+        if kh * kw > 1:
             return ops.SUM_BLOCKS
+        if cin >= 112 and stride == 1:
+            # a 1x1 layer: ATen's jit_1x1 kernel cuts the reduction of wide layers into blocks on some plane sizes
+            # (e.g. 256 -> 64 at 576x960: blocks of 96 channels); the rule follows from the shape of the call
+            return lambda n, h, w: aten_rules.conv1x1_sum_rule(cin, cout, n, h, w)
         return ops.SUM_CHAIN
 
     @contextlib.contextmanager
@@ -363,7 +371,7 @@ class HipEngine:
         if c is None:
             w = self.sd[p + ".weight"]
             c = ops.Conv2d(w, self.sd.get(p + ".bias"), stride, (padding, padding), self.dev,
-                           split=self.nsplit, rule=self.sum_rule(p, w))
+                           split=self.nsplit, rule=self.sum_rule(p, w, stride))
             torch.cuda.synchronize(self.dev)      # packed weights are used from several streams later
             self._convs[key] = c
         return c

@@ -76,15 +76,17 @@ class Conv2d:
     (Cin % 4 == 0) or kept OIHW for the small-Cin vector kernel."""
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), device="cuda", split=0, rule=SUM_CHAIN):
-        """rule: the layer's summation rule (SUM_CHAIN / SUM_BLOCKS, include/pmctf_hip.h) — part of the layer's arithmetic,
-        chosen by whoever owns the layer (HipEngine.sum_rule), never by the launch shape.
+        """rule: the layer's summation rule (SUM_CHAIN / SUM_BLOCKS / a reduce-block size B >= 16, include/pmctf_hip.h),
+        or a function (N, H, W) -> rule for layers whose rule follows from the reference tensor's shape (1x1 layers,
+        pMCTF.hip.aten_rules) — part of the layer's arithmetic, chosen by whoever owns the layer (HipEngine.sum_rule),
+        never by the launch shape.
         split = 1, 2 or 3: ALSO pack bf16-split weights for the auxiliary reduced-precision kernel (conv_split.hip) and
         use it on planes of at least SPLIT_MIN_PX output pixels when the shape is supported; 0 (default): exact f32 only."""
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.stride = int(stride)
-        self.rule = int(rule)
+        self.rule = rule if callable(rule) else int(rule)
         self.pad = (int(padding[0]), int(padding[1])) if isinstance(padding, (tuple, list)) else (int(padding),) * 2
         self.small = self.Cin <= 4
         L = _lib.hip()
@@ -140,9 +142,10 @@ class Conv2d:
         for r in (res1, res2):
             assert r is None or tuple(r.shape) == shp
         L = _lib.hip()
+        rule = self.rule(N, H, W) if callable(self.rule) else self.rule
         if self.few:
             _lib.check(L.pmctf_conv2d_fewcout_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
-                                                  self.Cout, self.KH, int(act), float(slope), self.rule, _stream()),
+                                                  self.Cout, self.KH, int(act), float(slope), rule, _stream()),
                        "conv2d_fewcout")
             return y
         probe = CONV_PROBE if (CONV_PROBE is not None and not torch.cuda.is_current_stream_capturing()
@@ -157,11 +160,11 @@ class Conv2d:
         elif self.small:
             _lib.check(L.pmctf_conv2d_smallcin_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
                                                    self.Cout, self.KH, self.KW, self.stride, self.pad[0], self.pad[1],
-                                                   int(act), float(slope), self.rule, _stream()), "conv2d_smallcin")
+                                                   int(act), float(slope), rule, _stream()), "conv2d_smallcin")
         else:
             _lib.check(L.pmctf_conv2d_nhwc_opts_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
                                                     self.Cout, self.KH, self.KW, self.stride, self.pad[0], self.pad[1],
-                                                    int(act), float(slope), self.rule, _opts(), _stream()), "conv2d")
+                                                    int(act), float(slope), rule, _opts(), _stream()), "conv2d")
         if probe is not None:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))

@@ -68,6 +68,10 @@ static void pm_parallel_for(long n, long chunk, pm_job_fn fn, void *ctx) {
  *                       out = (..((S_0 + bias) + S_1) + S_2 ..) + S_last
  *                       This is what ATen's CPU path (oneDNN 3.7.1 jit:avx512_core direct convolution) computes for every
  *                       KH*KW > 1 convolution of the path, measured bit for bit (tools/aten_conv_rules.py).
+ *   rule B >= 16 ("reduce-B"): blocks of B input channels (B a multiple of 16); the FIRST block's chain starts at the
+ *                       bias, later blocks start at zero; out = (..(T_0 + T_1) + ..) + T_last.  What oneDNN's jit_1x1
+ *                       kernel computes for the 1x1 layers whose reduction it blocks (B is its heuristic's choice for
+ *                       the shape; B >= Cin is rule 0).
  * ------------------------------------------------------------------------- */
 #define PM_XB 32 /* output columns kept in registers */
 typedef struct {
@@ -113,6 +117,27 @@ static void pm_conv_job(long job, void *vctx) {
             }
             _mm256_storeu_ps(acc, t0); _mm256_storeu_ps(acc + 8, t1);
             _mm256_storeu_ps(acc + 16, t2); _mm256_storeu_ps(acc + 24, t3);
+        } else if (c->rule >= 16) {
+            /* reduction blocked by c->rule channels (oneDNN jit_1x1 with a blocked reduction): the first block's chain
+             * starts at the bias, every later block's at zero; block results are added in turn */
+            const int B = c->rule;
+            float tot[PM_XB];
+            for (int j = 0; j < PM_XB; ++j) { acc[j] = b; tot[j] = 0.0f; }
+            for (int c0 = 0; c0 < Cin; c0 += PM_CB) {
+                const int c1 = c0 + PM_CB < Cin ? c0 + PM_CB : Cin;
+                if (c0 > 0 && c0 % B == 0)
+                    for (int j = 0; j < PM_XB; ++j) { tot[j] = c0 == B ? acc[j] : tot[j] + acc[j]; acc[j] = 0.0f; }
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx)
+                        for (int ci = c0; ci < c1; ++ci) {
+                            const float wv = w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+                            const float *restrict row = xp + (((long)n * Hc + (long)oy * stride + ky) * Cin + ci) * Wc +
+                                                        (long)xb * stride + kx;
+                            for (int j = 0; j < PM_XB; ++j) acc[j] = fmaf(row[(long)j * stride], wv, acc[j]);
+                        }
+            }
+            if (Cin > B)
+                for (int j = 0; j < PM_XB; ++j) acc[j] = tot[j] + acc[j];
         } else if (c->rule == 1) {
             float tot[PM_XB];
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {

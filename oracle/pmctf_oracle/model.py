@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import entropy
+from . import aten_rules, entropy
 from .kernels import CdefK, TorchK
 
 
@@ -81,7 +81,7 @@ class Oracle:
     SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
 
     @classmethod
-    def sum_rule(cls, p, x, w, groups=1):
+    def sum_rule(cls, p, x, w, groups=1, stride=1):
         """Summation rule of the PM-F32 back-end for the convolution with parameter key p (oracle/c/pm_ops.c: 0 = one chain
         from the bias, 1 = per-16-channel-block sums from zero added in turn, bias after the first block).  KH*KW > 1
         layers of the signal path (motion estimation, motion codec, temporal and spatial lifting) follow rule 1, which is
@@ -89,9 +89,12 @@ class Oracle:
         shape-dependent exception, also ATen's: a lifting step's 3x1 filter whose (reflect-padded) input is ONE plane of
         at most 20 480 elements does not go through oneDNN (Convolution.cpp `use_mkldnn`) but through im2col + gemv,
         which starts from the bias — rule 0."""
-        if groups != 1 or w.size(2) * w.size(3) == 1:
+        if groups != 1 or not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
             return 0
-        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+        if w.size(2) * w.size(3) == 1:
+            # 1x1 layers: one chain from the bias, unless ATen's jit_1x1 kernel blocks the reduction (aten_rules: B channels)
+            if w.size(1) >= 112 and stride == 1:
+                return aten_rules.conv1x1_sum_rule(w.size(1), w.size(0), x.size(0), x.size(2), x.size(3))
             return 0
         if w.size(0) == 1 and w.size(1) == 1 and w.size(3) == 1 and x.size(0) == 1 and x.numel() <= 20480:
             return 0
@@ -101,7 +104,7 @@ class Oracle:
         w = self.sd[p + ".weight"]
         if self.K.name == "cdef":
             return self.K.conv2d(x, w, self.sd.get(p + ".bias"), stride=stride, padding=padding, groups=groups,
-                                 rule=self.sum_rule(p, x, w, groups))
+                                 rule=self.sum_rule(p, x, w, groups, stride))
         return self.K.conv2d(x, w, self.sd.get(p + ".bias"), stride=stride, padding=padding, groups=groups)
 
     # ------------------------------------------------------------------ a6: PredictUpdate, lifting_1d.py:36-49

@@ -108,7 +108,7 @@ class MixedOracle(Oracle):
         w, b = self.sd[p + ".weight"], self.sd.get(p + ".bias")
         if self.pm(group_of(p)):        # PM-F32 with the summation rule the product gives this layer (Oracle.sum_rule)
             return self.K.c.conv2d(x.contiguous(), w, b, stride=stride, padding=padding, groups=groups,
-                                   rule=self.sum_rule(p, x, w, groups))
+                                   rule=self.sum_rule(p, x, w, groups, stride))
         return self.K.t.conv2d(x.contiguous(), w, b, stride=stride, padding=padding, groups=groups)
 
     def predict_update(self, p, x):
