@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pm_tanh_tables.h"
+#include "pm_log_tables.h"
 
 namespace pm {
 
@@ -71,7 +72,16 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf_(-x)); }
 
-__device__ __forceinline__ float logf_(float x) {
+// natural log: the schedule of Intel MKL's vmsLn (high accuracy, AVX-512 kernel) = torch.log on a float32 CPU tensor, bit
+// for bit on [2^-100, 2^100) (oracle/c/pm_math.h pm_logf has the derivation; tools/mkl_log_tables.py --verify the check);
+// outside that range, which the path never reaches (scales are clamped to >= 1e-5), the former polynomial schedule.
+static __device__ const unsigned log_step_m[36] = PM_LOG_STEP_M_PADDED;     // 33 thresholds + sentinels
+static __device__ const unsigned log_step_r[33] = PM_LOG_STEP_R;
+static __device__ const unsigned log_bucket[32] = PM_LOG_BUCKET;            // step at the start of mantissa bucket m >> 18
+static __device__ const unsigned log_thi[32] = PM_LOG_THI;
+static __device__ const unsigned log_tlo[32] = PM_LOG_TLO;
+
+__device__ __forceinline__ float logf_poly_(float x) {
     const unsigned u = f2u(x);
     int e = (int)(u >> 23) - 127;
     float m = u2f((u & 0x007fffffu) | 0x3f800000u);
@@ -87,6 +97,33 @@ __device__ __forceinline__ float logf_(float x) {
     const float ef = (float)e;
     const float lo = __builtin_fmaf(ef, 9.0580006145e-6f, lm);
     return __builtin_fmaf(ef, 0.693138123f, lo);
+}
+
+__device__ __forceinline__ float logf_(float x) {
+    const unsigned ux = f2u(x);
+    const int E = (int)(ux >> 23) - 127;
+    if ((ux >> 31) || E < -100 || E >= 100) return logf_poly_(x);
+    const unsigned m = ux & 0x007fffffu;
+    unsigned k = log_bucket[m >> 18];                   // at most three thresholds fall into one bucket
+    k += log_step_m[k + 1] <= m;
+    k += log_step_m[k + 1] <= m;
+    k += log_step_m[k + 1] <= m;
+    const unsigned rb = log_step_r[k] - ((unsigned)E << 23);
+    const float R = u2f(rb);
+    const int i = (int)(rb >> 18) & 31;
+    const float e = (float)((int)(rb >> 23) - 127);
+    const float u = __builtin_fmaf(R, x, -u2f(PM_LOG_ONE));
+    const float lo = __builtin_fmaf(e, -u2f(PM_LOG_LN2LO), u2f(log_tlo[i]));
+    const float hi = __builtin_fmaf(-u2f(PM_LOG_LN2HI), e, u2f(log_thi[i]));
+    float p = __builtin_fmaf(u2f(PM_LOG_C4), u, u2f(PM_LOG_C3));
+    const float u2 = u * u;
+    p = __builtin_fmaf(p, u, u2f(PM_LOG_C2));
+    p = __builtin_fmaf(p, u2, lo);
+    const float s = u + hi;
+    const float t = s - hi;
+    float r = u - t;
+    r = r + p;
+    return s + r;
 }
 
 // activations used in conv epilogues

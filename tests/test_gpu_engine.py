@@ -536,7 +536,9 @@ def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample
         import json
         os.makedirs(d, exist_ok=True)
         json.dump({k: out[k] for k in ("dbits", "psnr_err", "same", "diff", "lengths_equal", "bpp", "bpp_ref")},
-                  open(os.path.join(d, f"gop{gop}_q{q_index}{'' if sequence == 'pan' else '_' + sequence}.json"), "w"))
+                  open(os.path.join(d, f"gop{gop}_q{q_index}{'' if sequence == 'pan' else '_' + sequence}"
+                                       f"{'' if size == (1920, 1080) else '_%dx%d' % size}"
+                                       f"{'' if me_downsample == 1 else '_ds%d' % me_downsample}.json"), "w"))
     _headline_cache[key] = out
     del enc, rec, fr
     torch.cuda.empty_cache()
@@ -643,9 +645,6 @@ def test_2160p_pair_vs_reference(cuda):
     assert r["lengths_equal"]
 
 
-@pytest.mark.xfail(strict=True, reason="measured: frames 0 and 4 are one 32-bit rANS word longer than the reference's "
-                                       "(bit deltas [32, 0, 0, 0, 32, 0, 0, 0] of 4.97 / 4.20 Mbit; frame 4's in its motion stream), max PSNR error 3.4e-5 dB "
-                                       "(last-bit rounding of conv sums, PM-F32 vs ATen; pinned exactly by the test below)")
 def test_1366x768_gop8_vs_reference(cuda):
     """A frame size that is a multiple of nothing the path tiles by (1366x768 -> padded to 1408x768; chroma 683x384): GOP 8,
     q_index 3, four ME stages against the digest of the real reference's CPU run (tools/make_golden.py --gop_only --width
@@ -659,12 +658,12 @@ def test_1366x768_gop8_vs_reference(cuda):
 
 
 def test_1366x768_gop8_pinned_deviation(cuda):
-    """What the strict test above measured, pinned exactly: any drift (better or worse) fails."""
+    """What the strict test above measured, pinned: bits of every frame and of every motion stream equal to the
+    reference's; the count of files whose bytes differ at equal length (symbols / CDF rows inside, from the
+    entropy-parameter networks' last bits) may only move with a change of the arithmetic."""
     r = _headline_run(8, 3, size=(1366, 768))
-    assert r["dbits"] == [32, 0, 0, 0, 32, 0, 0, 0]
-    # frame 4's extra word is in its motion stream, frame 0's in the L subband stream
-    assert [int(a - b) for a, b in zip(r["bits_mv"], r["ref_bits_mv"])] == [0, 0, 0, 0, 32, 0, 0, 0]
-    assert r["psnr_err"] < 1e-4 and r["same"] == 16 and r["diff"] == 7
+    assert r["dbits"] == [0] * 8 and r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4 and r["same"] == 20 and r["diff"] == 3
 
 
 def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
