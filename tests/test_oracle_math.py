@@ -55,3 +55,68 @@ def test_resampling_matches_aten():
                         align_corners=True).numpy()
     mine = clib.flow_warp(im.numpy(), flow.numpy(), lx.numpy(), ly.numpy())
     assert np.abs(ref - mine).max() < 1e-4
+
+
+def test_tanh_and_log_are_the_reference_s_bit_for_bit():
+    """pm_tanhf / pm_logf restate the schedules of MKL's vmsTanh / vmsLn (= torch.tanh / torch.log on the machine the
+    fixtures were generated on; tools/mkl_tanh_tables.py / mkl_log_tables.py --verify checked every input there).  Here:
+    against a fixture of torch's own outputs (tests/golden/reference_torch_tanh_log.npz), and against the torch of the
+    machine the test runs on wherever that torch still agrees with the fixture (another CPU may dispatch another kernel)."""
+    import os
+    from pmctf_oracle import clib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_torch_tanh_log.npz"))
+    assert np.array_equal(clib.tanh(g["tanh_x"]).view(np.uint32), g["tanh_y"].view(np.uint32))
+    assert np.array_equal(clib.log(g["log_x"]).view(np.uint32), g["log_y"].view(np.uint32))
+    here_t = torch.tanh(torch.from_numpy(g["tanh_x"])).numpy()
+    here_l = torch.log(torch.from_numpy(g["log_x"])).numpy()
+    if np.array_equal(here_t.view(np.uint32), g["tanh_y"].view(np.uint32)) and \
+            np.array_equal(here_l.view(np.uint32), g["log_y"].view(np.uint32)):
+        r = np.random.default_rng(11)
+        x = (r.standard_normal(2_000_000) * 2).astype(np.float32)
+        assert np.array_equal(clib.tanh(x).view(np.uint32), torch.tanh(torch.from_numpy(x)).numpy().view(np.uint32))
+        s = np.exp(r.uniform(np.log(1e-5), np.log(1e5), 2_000_000)).astype(np.float32)
+        assert np.array_equal(clib.log(s).view(np.uint32), torch.log(torch.from_numpy(s)).numpy().view(np.uint32))
+
+
+def test_signal_path_convolutions_are_aten_s_bit_for_bit():
+    """The summation rules of the signal path (oracle/c/pm_ops.c rule 1 for KH*KW > 1, the chain or oneDNN's blocked
+    reduction for 1x1: pmctf_oracle.aten_rules) reproduce F.conv2d bit for bit on the layer shapes of the path — checked
+    live where this machine's ATen is the fixtures' (oneDNN avx512_core: the 3x3 probe below tells), skipped elsewhere."""
+    import pytest
+    from pmctf_oracle import aten_rules, clib
+    g = torch.Generator().manual_seed(5)
+    cases = [(1, 1, 74, 240, 1, 3, 1, 1, 0, 0), (2, 1, 38, 120, 1, 3, 1, 1, 0, 0), (1, 1, 72, 240, 16, 3, 3, 1, 1, 1),
+             (1, 16, 72, 120, 16, 3, 3, 1, 1, 1), (1, 16, 64, 96, 1, 3, 3, 1, 1, 1), (1, 8, 36, 60, 32, 7, 7, 1, 3, 3),
+             (1, 32, 36, 60, 64, 7, 7, 1, 3, 3), (1, 64, 72, 120, 64, 3, 3, 2, 1, 1), (1, 2, 144, 240, 64, 3, 3, 2, 1, 1),
+             (1, 256, 64, 96, 64, 1, 1, 1, 0, 0), (1, 128, 72, 128, 64, 1, 1, 1, 0, 0), (1, 768, 72, 120, 192, 1, 1, 1, 0, 0),
+             (1, 192, 16, 32, 192, 1, 1, 1, 0, 0), (1, 64, 72, 120, 256, 1, 1, 1, 0, 0)]
+    first = True
+    for (n, cin, h, w, cout, kh, kw, s, ph, pw) in cases:
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(x, wt, b, stride=s, padding=(ph, pw)).numpy()
+        if kh * kw > 1:
+            rule = 0 if (cin == 1 and cout == 1 and kw == 1 and n == 1 and x.numel() <= 20480) else 1
+        else:
+            rule = aten_rules.conv1x1_sum_rule(cin, cout, n, h, w)
+        y = clib.conv2d(x.numpy(), wt.numpy(), b.numpy(), s, (ph, pw), rule)
+        same = np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+        if first and not same:
+            pytest.skip("this machine's ATen convolution is not the fixtures' (other oneDNN ISA path)")
+        first = False
+        assert same, (n, cin, h, w, cout, kh, kw, s, rule)
+
+
+def test_aten_rule_predictor_has_one_definition():
+    """the product carries its own copy of the shape rule (pMCTF/hip/aten_rules.py); it must equal the oracle's"""
+    import itertools
+    from pmctf_oracle import aten_rules as a
+    from pMCTF.hip import aten_rules as b
+    for cin, cout, (h, w) in itertools.product((64, 112, 128, 192, 256, 384, 512, 768), (64, 128, 192, 256, 768),
+                                               ((18, 30), (36, 60), (72, 120), (144, 240), (288, 480), (576, 960), (24, 44),
+                                                (48, 88), (96, 176), (192, 352), (16, 32), (32, 64), (64, 128), (27, 48),
+                                                (28, 48), (10, 300), (11, 300), (1088, 1920))):
+        assert a.conv1x1_sum_rule(cin, cout, 1, h, w) == b.conv1x1_sum_rule(cin, cout, 1, h, w)
+    assert a.onednn_1x1_reduce_block(256, 64, 576, 960) == 96 and a.onednn_1x1_reduce_block(768, 192, 72, 120) == 512
+    assert a.onednn_1x1_reduce_block(192, 192, 16, 32) == 80 and a.onednn_1x1_reduce_block(256, 64, 144, 240) == 256
