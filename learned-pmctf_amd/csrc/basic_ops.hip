@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void conv3x3_smallcin_strip_kernel(const float
 __global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                                  const float *__restrict__ bias, float *y, float *y2,
                                                                  int N, int H, int W, int act2, float slope, int rule) {
+    __shared__ uint4 tanh_tab[pm::TANH_LDS_UINT4];
+    pm::tanh_rows_to_lds(tanh_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const long total = (long)N * H * W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ox = (int)(pm_mod(idx, W));
@@ -222,8 +225,11 @@ __global__ __launch_bounds__(256) void conv3x3_cin1_pix16_kernel(const float *__
             *(float4 *)(y + idx * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
             if (y2)
                 *(float4 *)(y2 + idx * 16 + q * 4) =
-                    make_float4(pm::apply_act(v[0], act2, slope), pm::apply_act(v[1], act2, slope),
-                                pm::apply_act(v[2], act2, slope), pm::apply_act(v[3], act2, slope));
+                    act2 == pm::ACT_TANH
+                        ? make_float4(pm::tanhf_rows(v[0], tanh_tab), pm::tanhf_rows(v[1], tanh_tab),
+                                      pm::tanhf_rows(v[2], tanh_tab), pm::tanhf_rows(v[3], tanh_tab))
+                        : make_float4(pm::apply_act(v[0], act2, slope), pm::apply_act(v[1], act2, slope),
+                                      pm::apply_act(v[2], act2, slope), pm::apply_act(v[3], act2, slope));
         }
     }
 }

@@ -42,16 +42,32 @@ struct ConvArgs {
     // mtp: cout tiles per packed M-block (the weight layout); a workgroup handles MT <= mtp of them, blockIdx.z
     // enumerates groups of MT tiles.  [oy_base, oy_end): output rows this launch covers.
     int mtp, oy_base, oy_end;
-    // summation rule (see the header): bsum 0 = one chain from the bias; bsum 1 = the reduction is cut into blocks of
-    // `bchunks` 16-channel chunks whose sums are added in turn — bias_first 0: every block's chain starts at zero and the
-    // bias is added to the first block's sum (ATen's KH*KW > 1 layers, bchunks = 1); bias_first 1: the first block's chain
-    // starts at the bias, later blocks at zero (ATen's 1x1 layers with a blocked reduction, bchunks = block / 16)
-    int bsum, bchunks, bias_first;
 };
 
+// Summation rule of a launch (see the header), a SEPARATE kernel argument of the kernels that implement rule 1: the
+// register-tight rule-0 kernels (conv3x3s1_wave_kernel<7,2> sits at the VGPR and SGPR limits) must not grow by a word.
+// bsum 0 = one chain from the bias; bsum 1 = the reduction is cut into blocks of `bchunks` 16-channel chunks whose sums
+// are added in turn — bias_first 0: every block's chain starts at zero and the bias is added to the first block's sum
+// (ATen's KH*KW > 1 layers, bchunks = 1); bias_first 1: the first block's chain starts at the bias, later blocks at zero
+// (ATen's 1x1 layers with a blocked reduction, bchunks = block / 16)
+struct SumCfg { int bsum, bchunks, bias_first; };
+thread_local SumCfg t_sum = {0, 1, 0};      // of the convolution call in progress on this host thread
+
 // MT: cout tiles per workgroup, NT: pixel tiles per wave, TW16: 16-pixel segments per tile row.
-template <int MT, int NT, int TW16, bool BSUM = false>
+template <int MT, int NT, int TW16, bool BSUM>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const SumCfg sc);
+
+template <int MT, int NT, int TW16>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    conv_mfma_body<MT, NT, TW16, false>(a, SumCfg{0, 1, 0});
+}
+template <int MT, int NT, int TW16>
+__global__ __launch_bounds__(256) void conv_mfma_bsum_kernel(ConvArgs a, SumCfg sc) {
+    conv_mfma_body<MT, NT, TW16, true>(a, sc);
+}
+
+template <int MT, int NT, int TW16, bool BSUM>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, const SumCfg sc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TW = TW16 * 16;
     constexpr int TH = NT * WAVES / TW16;
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = (BSUM && !a.bias_first) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = (BSUM && !sc.bias_first) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
         }
@@ -133,15 +149,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         }
         if constexpr (BSUM) {
-            if ((cb + 1) % a.bchunks == 0 || cb + 1 == a.ncb) {     // a block's sum is complete (wave-uniform)
-                const bool first = cb < a.bchunks;
+            if ((cb + 1) % sc.bchunks == 0 || cb + 1 == a.ncb) {     // a block's sum is complete (wave-uniform)
+                const bool first = cb < sc.bchunks;
                 const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const f32x4 b = *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        tot[mt][nt] = first ? (a.bias_first ? acc[mt][nt] : acc[mt][nt] + b) : tot[mt][nt] + acc[mt][nt];
+                        tot[mt][nt] = first ? (sc.bias_first ? acc[mt][nt] : acc[mt][nt] + b) : tot[mt][nt] + acc[mt][nt];
                         acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pipe_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int seg = wave * NT + nt;
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_mfma_wave_kernel(
         if (more) stash(wlds + (NBUF == 2 ? ((cb + 1) & 1) * bufsz : 0));
     }
 
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + (lane & 15);
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
         if (more) stash(NBUF == 2 ? ((cb + 1) & 1) : 0);
     }
 
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + (lane & 15);
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
         const int oy = oy0 + wave, ox = ox0 + (lane & 15);
         if (oy < a.oy_end && ox < a.Wo) {
             const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-            PM_EPILOGUE(a,
+            PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
             for (int mt = 0; mt < MT; ++mt) {
                 const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
@@ -936,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void conv7x7s1_pipe_kernel(ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
     }
 
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = oy0 + (NT == 4 ? 2 * wave + (nt >> 1) : wave), ox = ox0 + 16 * (nt & 1) + (lane & 15);
@@ -1058,7 +1074,7 @@ __global__ __launch_bounds__(256) void conv_mfma_res_kernel(ConvArgs a) {
     const int oy = oy0 + wave, ox = ox0 + (lane & 15);
     if (oy >= a.oy_end || ox >= a.Wo) return;
     const size_t pbase = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout;
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int mt = 0; mt < MT; ++mt) {
         const int co = (mtile0 + mt) * 16 + 4 * (lane >> 4);
@@ -1073,7 +1089,7 @@ _Pragma("unroll")
 // weight fragments stay in registers and a wave is PERSISTENT: it walks over 4x16-pixel tiles (grid-stride), fetching
 // the next tile's patch into registers while the current one is multiplied, wave-private LDS, no barriers.  The layer
 // moves 128 B per pixel for 9.2 kFLOP, i.e. it is HBM-bound once the weights stop being re-read.  Same sums, same order.
-__global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int tiles_total) {
+__global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int tiles_total, int bsum) {
     constexpr int NT = 4, LH = 6, LW = 18, E = LH * LW * 4, MAXP = (E + 63) / 64;      // 432 float4 slots, 7 per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -1141,7 +1157,7 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
         if (more) fetch(tile + stride);
         f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = a.bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float *bb = cur + ((t / 3) * LW + (t % 3)) * CP;
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
             }
         }
-        if (a.bsum) {           // rule 1, one chunk: the chain ran from zero, the bias is added last
+        if (bsum) {             // rule 1, one chunk: the chain ran from zero, the bias is added last
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] + bias;
         }
@@ -1190,9 +1206,14 @@ __global__ __launch_bounds__(256) void conv16_persistent_kernel(ConvArgs a, int 
 // own contiguous band of tiles, so the halo rows of a tile are found in the L2 that fetched them one round earlier.
 // Same sums, same order.
 template <int OCC>
-__global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int tiles_total) {
+__global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int tiles_total, int bsum) {
     constexpr int NT = 4, LH = 6, LW = 18, E = LH * LW * 4, MAXP = (E + 63) / 64;      // 432 float4 slots, 7 per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ uint4 tanh_tab[pm::TANH_LDS_UINT4];              // the PredictUpdate trunk's activation (one barrier, at the start)
+    if (a.act == pm::ACT_TANH) {                                // wave-uniform
+        pm::tanh_rows_to_lds(tanh_tab, threadIdx.x, 256);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int bufsz = LH * LW * CP;
@@ -1281,7 +1302,7 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
                 f32x4 v = acc[nt];
                 if (a.act == pm::ACT_TANH) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = pm::tanhf_(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = pm::tanhf_rows(v[i], tanh_tab);
                 } else if (a.act != pm::ACT_NONE) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = pm::apply_act(v[i], a.act, a.slope);
@@ -1307,7 +1328,7 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
         if (prev >= 0) finish(prev);
         if (tile + stride < t_end) fetch(tile + stride);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = a.bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = bsum ? f32x4{0.f, 0.f, 0.f, 0.f} : bias;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float *bb = wlds + ((t / 3) * LW + (t % 3)) * CP + boff;
@@ -1321,7 +1342,7 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][ks], b[nt], acc[nt], 0, 0, 0);
             }
         }
-        if (a.bsum) {           // rule 1, one chunk: the chain ran from zero, the bias is added last
+        if (bsum) {             // rule 1, one chunk: the chain ran from zero, the bias is added last
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = acc[nt] + bias;
         }
@@ -1428,7 +1449,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int ti
         __syncthreads();
     }
 
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < NT; ++nt) {
         const long p = p0 + nt * 16 + (lane & 15);
@@ -1527,12 +1548,19 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
     const size_t smem = (size_t)LH * LW * CP * sizeof(float);
     if (smem > 160 * 1024) return PMCTF_EINVAL;
     dim3 grid(b.tiles_x * b.tiles_y, a.N, gz);
-    if (a.bsum) {
+    const SumCfg sc = t_sum;
+    if (a.act > pm::ACT_LEAKY && !sc.bsum) {    // tanh / sigmoid epilogues live in the generic kernel only (conv_epilogue.h)
+        static std::once_flag once_t;
+        allow_big_lds(conv_mfma_kernel<MT, NT, TW16>, once_t);
+        CONV_LAUNCH((conv_mfma_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b);
+        return pm_launch_status();
+    }
+    if (sc.bsum) {
         // rule 1 (per-chunk sums): the 7x7 pipelined kernel where it applies (SpyNet), else the single-buffer kernel;
         // the specialised 3x3 / wave-private kernels carry rule 0 only (their layers of the path that need rule 1 have at
         // most 64 couts and are a few per cent of the work)
         if constexpr (((NT == 4 && TW16 == 2) || (NT == 1 && TW16 == 1)) && MT <= 4) {
-            if (a.bchunks == 1 && !a.bias_first && a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 &&
+            if (a.act <= pm::ACT_LEAKY && sc.bchunks == 1 && !sc.bias_first && a.KH == 7 && a.KW == 7 && a.S == 1 && (a.Cin % CB) == 0 &&
                 knob("K77") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
                 static std::once_flag once_7b;
                 allow_big_lds(conv7x7s1_pipe_kernel<MT, NT, true>, once_7b);
@@ -1542,8 +1570,8 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         }
         if constexpr (MT <= 4 || NT <= 2) {
             static std::once_flag once_sb;
-            allow_big_lds(conv_mfma_kernel<MT, NT, TW16, true>, once_sb);
-            CONV_LAUNCH((conv_mfma_kernel<MT, NT, TW16, true>), grid, dim3(256), smem, st, b);
+            allow_big_lds(conv_mfma_bsum_kernel<MT, NT, TW16>, once_sb);
+            CONV_LAUNCH((conv_mfma_bsum_kernel<MT, NT, TW16>), grid, dim3(256), smem, st, b, sc);
             return pm_launch_status();
         } else {
             return launch<MT, 2, 1>(a, gz, st, r0, r1);     // wide M-blocks: 2 segments per wave keep both accumulator sets in registers
@@ -1673,14 +1701,14 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st, const LaunchOpts &lo) {
                     if (g > 256 * occ) g = 256 * occ;
                     const size_t smem1 = (size_t)6 * 18 * CP * sizeof(float) * WAVES;
                     note_launch("conv16_band_kernel", (int)occ, 1, 1, dim3((unsigned)g));
-                    if (occ == 2) { PM_LAUNCH(conv16_band_kernel<2>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
-                    else if (occ == 3) { PM_LAUNCH(conv16_band_kernel<3>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
-                    else { PM_LAUNCH(conv16_band_kernel<4>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles); }
+                    if (occ == 2) { PM_LAUNCH(conv16_band_kernel<2>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles, t_sum.bsum); }
+                    else if (occ == 3) { PM_LAUNCH(conv16_band_kernel<3>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles, t_sum.bsum); }
+                    else { PM_LAUNCH(conv16_band_kernel<4>, dim3((unsigned)g), dim3(256), smem1, st, b, (int)tiles, t_sum.bsum); }
                     return pm_launch_status();
                 }
                 const size_t smem = (size_t)6 * 18 * CP * sizeof(float) * 2 * WAVES;
                 note_launch("conv16_persistent_kernel", 1, 1, 1, dim3((unsigned)wgs));
-                PM_LAUNCH(conv16_persistent_kernel, dim3((unsigned)wgs), dim3(256), smem, st, b, (int)tiles);
+                PM_LAUNCH(conv16_persistent_kernel, dim3((unsigned)wgs), dim3(256), smem, st, b, (int)tiles, t_sum.bsum);
                 return pm_launch_status();
             }
         }
@@ -1693,11 +1721,11 @@ int dispatch_tile(ConvArgs a, int MB, hipStream_t st, const LaunchOpts &lo) {
     // (2x288x480 -> 2x144x240: 324 -> 177 us; tools/bench_conv.py "s2small")
     const bool s2_whole = MTP >= 7 && a.S == 2 && a.KH == 3 && a.KW == 3 && (a.Cin % CB) == 0 && knob("K33") != 0 && px >= 8000;
     if (MTP >= 2 && px <= msplit_px && !s2_whole) {
-        if (knob("RES") == 1 && !a.bsum) {
+        if (knob("RES") == 1 && !t_sum.bsum && a.act <= pm::ACT_LEAKY) {
             const int rc = launch_res<1>(a, MTP * MB, st);
             if (rc != PMCTF_EINVAL) return rc;
         }
-        if (knob("RES") == 2 && !a.bsum) {
+        if (knob("RES") == 2 && !t_sum.bsum && a.act <= pm::ACT_LEAKY) {
             const int rc = launch_res<MTP>(a, MB, st);
             if (rc != PMCTF_EINVAL) return rc;
         }
@@ -1860,15 +1888,16 @@ extern "C" int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *wp, 
     a.act = act; a.slope = slope;
     a.tiles_x = a.tiles_y = 0;
     a.mtp = 1; a.oy_base = 0; a.oy_end = Ho;
-    a.bsum = 0; a.bchunks = 1; a.bias_first = 0;
-    if (sum_rule == PMCTF_SUM_BLOCKS) a.bsum = 1;
-    else if (sum_rule >= 16 && sum_rule < Cin) { a.bsum = 1; a.bchunks = sum_rule / CB; a.bias_first = 1; }   // >= Cin: one block = the chain
+    SumCfg sc = {0, 1, 0};
+    if (sum_rule == PMCTF_SUM_BLOCKS) sc.bsum = 1;
+    else if (sum_rule >= 16 && sum_rule < Cin) { sc.bsum = 1; sc.bchunks = sum_rule / CB; sc.bias_first = 1; }   // >= Cin: one block = the chain
+    t_sum = sc;
     int MT, MB;
     choose_mt(Cout, MT, MB);
     hipStream_t st = (hipStream_t)stream;
     g_last_len = 0;
     g_last_launch[0] = 0;
-    if (!a.bsum && KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
+    if (!sc.bsum && act <= pm::ACT_LEAKY && KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
         knob("K11") != 0 && MT * MB >= knob("K11_MIN_TILES")) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
         a.mtp = MT;
         return launch_1x1(a, MT * MB, st);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_split_kernel(SplitArgs a) 
     }
 
     // ---- epilogue (as conv_mfma.hip): lane holds couts 4g..4g+3 of pixel p of each of its four rows
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_split_wave_kernel(SplitArgs 
         }
         if (more) stash();       // in-order LDS: after this wave's last read of the chunk
     }
-    PM_EPILOGUE(a,
+    PM_EPILOGUE_NOTRANS(a,
 _Pragma("unroll")
     for (int nt = 0; nt < 4; ++nt) {
         const int oy = oy0 + nt, ox = ox0 + p;
@@ -500,7 +500,7 @@ extern "C" int pmctf_conv3x3_split_f32(const float *x, const uint16_t *w_packed,
                                        int Cout, int nsplit, int act, float slope, void *stream) {
     int MT, MB;
     if (!x || !w_packed || !bias_packed || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 16 ||
-        !split_shape(Cout, MT, MB) || N > 65535)
+        !split_shape(Cout, MT, MB) || N > 65535 || act < 0 || act > 2)      // none / relu / leaky (conv_epilogue.h act_c<-2>)
         return PMCTF_EINVAL;
     SplitArgs a;
     a.x = x; a.wp = w_packed; a.bp = bias_packed; a.res1 = res1; a.res2 = res2; a.y = y;
@@ -526,7 +526,7 @@ extern "C" int pmctf_conv3x3_split_geom_f32(const float *x, const uint16_t *w_pa
     int MT, MB;
     if (!x || !w_packed || !bias_packed || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 16 ||
         !split_shape(Cout, MT, MB) || MT != 7 || N > 65535 || stride != 2 || Ho <= 0 || Wo <= 0 || pad_h < 0 ||
-        pad_w < 0 || pad_h > 1 || pad_w > 1 || 2 * (Ho - 1) - pad_h >= H || 2 * (Wo - 1) - pad_w >= W)
+        pad_w < 0 || pad_h > 1 || pad_w > 1 || 2 * (Ho - 1) - pad_h >= H || 2 * (Wo - 1) - pad_w >= W || act < 0 || act > 2)
         return PMCTF_EINVAL;
     SplitArgs a;
     a.x = x; a.wp = w_packed; a.bp = bias_packed; a.res1 = res1; a.res2 = res2; a.y = y;

@@ -272,19 +272,22 @@ __global__ void ffn3_mix_kernel(const float *__restrict__ x, float *y, long P, i
 // LSTM2D gates (long_context.py:20-33): f = sigmoid(xh); cell' = f*cell + f*tanh(xh); hidden' = f*tanh(cell')
 __global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__restrict__ cell, float *cell_out,
                                   float *hid_out, long P, int C, int Cc) {
+    __shared__ uint4 tanh_tab[pm::TANH_LDS_UINT4];
+    pm::tanh_rows_to_lds(tanh_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const long total = P * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = (int)(pm_mod(idx, C));
         const long p = pm_div(idx, C);
         const float v = xh[idx];
         const float g = pm::sigmoidf_(v);
-        const float ct = pm::tanhf_(v);
+        const float ct = pm::tanhf_rows(v, tanh_tab);
         const float cprev = cell[p * Cc + (Cc == 1 ? 0 : c)];
         const float t1 = g * cprev;
         const float t2 = g * ct;
         const float cn = t1 + t2;
         cell_out[idx] = cn;
-        hid_out[idx] = g * pm::tanhf_(cn);
+        hid_out[idx] = g * pm::tanhf_rows(cn, tanh_tab);
     }
 }
 

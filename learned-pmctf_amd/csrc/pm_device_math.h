@@ -45,13 +45,16 @@ __device__ __forceinline__ float expf_(float x) {
 struct __attribute__((aligned(16))) TanhRow { unsigned w[12]; };
 static __device__ const TanhRow tanh_rows[32] = PM_TANH_TABLE_BY_INTERVAL;
 
-__device__ __forceinline__ float tanhf_(float x) {
+// rows: the 32 x 48-byte interval table, in global memory (tanh_rows) or copied to LDS by the workgroup (tanh_rows_to_lds:
+// the kernels that take tanh of every value keep it there — three 16-byte LDS reads per value instead of three divergent
+// global loads: pu_fused 567 -> see DESIGN, conv3x3_cin1_pix16 162 -> ..)
+__device__ __forceinline__ float tanhf_rows(float x, const uint4 *rows) {
     const unsigned ux = f2u(x);
     const unsigned ix = ux & PM_TANH_EXPMASK;
     int t = (int)(ix - PM_TANH_BIAS);
     t = t < 0 ? 0 : t;
     t = t > (int)PM_TANH_IDXMAX ? (int)PM_TANH_IDXMAX : t;
-    const uint4 *row = (const uint4 *)tanh_rows[t >> 21].w;
+    const uint4 *row = rows + 3 * (t >> 21);
     const uint4 r0 = row[0], r1 = row[1], r2 = row[2];        // B T_hi T_lo C1 | C3 C4 C5 C6 | C7 - - -
     const float y = u2f(ux & PM_TANH_ABS) - u2f(r0.x);
     float p = u2f(r2.x);
@@ -68,6 +71,15 @@ __device__ __forceinline__ float tanhf_(float x) {
         r = nan ? x + x : u2f((ux & PM_TANH_SIGN) | 0x3f800000u);
     }
     return r;
+}
+
+__device__ __forceinline__ float tanhf_(float x) { return tanhf_rows(x, (const uint4 *)tanh_rows[0].w); }
+
+constexpr int TANH_LDS_UINT4 = 96;                            // 32 rows x 3
+// every thread of the workgroup calls this, then __syncthreads(): dst = the table in LDS
+__device__ __forceinline__ void tanh_rows_to_lds(uint4 *dst, int tid, int nthreads) {
+    const uint4 *src = (const uint4 *)tanh_rows[0].w;
+    for (int i = tid; i < TANH_LDS_UINT4; i += nthreads) dst[i] = src[i];
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf_(-x)); }

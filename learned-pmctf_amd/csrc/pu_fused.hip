@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
 #ifdef PMCTF_PU_PROFILE
     long long t_prev_ = clock64();
 #endif
+    __shared__ uint4 tanh_tab[pm::TANH_LDS_UINT4];
+    pm::tanh_rows_to_lds(tanh_tab, threadIdx.x, 256);          // visible after the barrier behind phase 0
     float *in = lds + LDS_IN, *sk = lds + LDS_SK, *A1 = lds + LDS_A1, *A2 = lds + LDS_A2;
     float *A3 = A1;                                   // layer-3 output reuses the (dead) tanh(c1) buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = __builtin_fmaf(iv[j][t], wq[i][t], acc);
                 if (a.rule) acc = acc + bq[i];
-                v[i] = ok[j] ? pm::tanhf_(acc) : 0.0f;
+                v[i] = ok[j] ? pm::tanhf_rows(acc, tanh_tab) : 0.0f;
             }
             float2 *dst = (float2 *)(A1 + idx * CP + 4 * q);
             dst[0] = make_float2(v[0], v[1]);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void pu_fused_kernel(PuArgs a) {
         const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = inside ? pm::tanhf_(acc[i]) : 0.0f;
+        for (int i = 0; i < 4; ++i) v[i] = inside ? pm::tanhf_rows(acc[i], tanh_tab) : 0.0f;
         float2 *dst = (float2 *)(A2 + idx * CP + 4 * (lane >> 4));
         dst[0] = make_float2(v[0], v[1]);
         dst[1] = make_float2(v[2], v[3]);

@@ -153,7 +153,8 @@ class Conv2d:
         if probe is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.split and N * H * W >= SPLIT_MIN_PX:        # auxiliary reduced-precision profile (never the parity path)
+        use_split = self.split and N * H * W >= SPLIT_MIN_PX and int(act) <= ACT_LEAKY
+        if use_split:                                       # auxiliary reduced-precision profile (never the parity path)
             _lib.check(L.pmctf_conv3x3_split_f32(_p(x), C.c_void_p(self.w16.data_ptr()), _p(self.b), _p(res1), _p(res2),
                                                  _p(y), N, H, W, Cin, self.Cout, self.split, int(act), float(slope),
                                                  _stream()), "conv3x3_split")
@@ -168,7 +169,7 @@ class Conv2d:
         if probe is not None:
             e1.record()
             probe["events"].append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2] * self.Cout * Cin * self.KH * self.KW))
-            if "kernels" in probe and not (self.split and N * H * W >= SPLIT_MIN_PX):
+            if "kernels" in probe and not use_split:
                 buf = C.create_string_buffer(512)
                 L.pmctf_conv2d_last_launch(buf, 512)
                 probe["kernels"][buf.value.decode()] = probe["kernels"].get(buf.value.decode(), 0) + 1
@@ -379,7 +380,7 @@ def conv_at_class(conv, x, cls, act=ACT_NONE, slope=0.0, res1=None, res2=None):
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if conv.split and conv.Cout == 112 and y.shape[0] * y.shape[1] * y.shape[2] >= SPLIT_MIN_PX:      # auxiliary profile
+    if conv.split and conv.Cout == 112 and y.shape[0] * y.shape[1] * y.shape[2] >= SPLIT_MIN_PX and int(act) <= ACT_LEAKY:
         _lib.check(_lib.hip().pmctf_conv3x3_split_geom_f32(_p(x), C.c_void_p(conv.w16.data_ptr()), _p(conv.b), _p(res1),
                                                            _p(res2), _p(y), N, H, W, Cin, conv.Cout, conv.split, 2, 1 - py,
                                                            1 - px, H // 2, W // 2, int(act), float(slope), _stream()),

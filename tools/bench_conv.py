@@ -74,7 +74,7 @@ def main():
             continue
         w = torch.randn(Cout, Cin, K, K) * 0.05
         b = torch.randn(Cout)
-        conv = ops.Conv2d(w, b, S, (P, P))
+        conv = ops.Conv2d(w, b, S, (P, P), rule=int(os.environ.get("BENCH_RULE", "0")))   # summation rule (PMCTF_SUM_*)
         x = torch.randn(N, H, W, Cin, device="cuda")
         if os.environ.get("BENCH_RELU_INPUT"):     # activations as a ReLU leaves them (half zeros)
             x = torch.relu(x)
