@@ -71,6 +71,18 @@ if len(sys.argv) > 1:                       # per-launch durations of one signat
                   f"{[(f'gen{g}', f'{1e3 * dt:.1f} ms') for ts, dt, g in gc_log if t0 <= ts <= t1] or 'none'}")
     big = sorted(gc_log, key=lambda r: -r[1])[:5]
     print("longest collections of the probed run:", [(f"gen{g}", f"{1e3 * dt:.1f} ms") for _, dt, g in big])
+    import bisect
+    print("every collection of Python's cyclic GC that took more than 5 ms, and the probed convolution it interrupted (the "
+          "host stops between the start marker and the launch: the GPU idles, the marker pair reads the pause):")
+    for ts, dt, g in gc_log:
+        if dt > 5e-3:
+            i = bisect.bisect_right(host_t, ts) - 1
+            if 0 <= i < len(sigs):
+                (n_, h_, w_, ci_), co_, k_, st_ = sigs[i]
+                e0, e1, _ = probe["events"][i]
+                print(f"  gen{g} {1e3 * dt:.1f} ms inside launch #{i}: {n_}x{h_}x{w_} {ci_}->{co_} k{k_} s{st_}, whose markers read "
+                      f"{e0.elapsed_time(e1) * 1e3:.0f} us (median of its signature: "
+                      f"{sorted(round(a.elapsed_time(b) * 1e3) for s2, (a, b, _) in zip(sigs, probe['events']) if s2 == sigs[i])[len([1 for s2 in sigs if s2 == sigs[i]]) // 2]} us)")
 if os.environ.get("CENSUS_SMALL"):
     print("--- planes of at most 70 000 output pixels, by time ---")
     small = [(s, a) for s, a in agg.items() if s[0][0] * (s[0][1] // s[3]) * (s[0][2] // s[3]) <= 70000]
