@@ -397,7 +397,7 @@ def main():
         # done by now) and every rank leaves without waiting for the others.
         import threading
 
-        headline_line = dict(out)              # snapshot: the main thread keeps filling `out` while the timer runs
+        headline_line = dict(out) if rank == 0 else {}      # snapshot: the main thread keeps filling `out` while the timer runs
 
         def bail():
             # the line survives (the timed region and its roofline are done), the STATUS does not: a hung collective or
@@ -433,7 +433,10 @@ def main():
                             "relay_hops": stats.get("relay_hops"), "relay_bytes_per_hop": stats.get("relay_bytes_per_hop"),
                             "collective": "all_gather_into_tensor (RCCL)" if dist.get_backend() == "nccl" else "all_gather (gloo)",
                             "schedule": "ONE GOP: pair k of a temporal stage on rank k mod N, motion context relayed rank to "
-                                        "rank, one all-gather of the subband tree per stage",
+                                        "rank, one all-gather of the subband tree per stage; a stage with at most half as "
+                                        "many pairs as ranks is shared in PARTS (motion + luma coders / chroma coders, in the "
+                                        "last stage H and L coders on separate ranks) and reassembled by broadcasts of the "
+                                        "live tensors only (pmctf_dist.pair_parts)",
                             "bits_identical_to_rank0_gop": (last["ps"]["bits"] == last["enc"]["bits"]) if rank == 0 else None}
             # closed GOPs in flight: 0 = as many as keep every rank busy in every stage (N / 2: the late stages of a
             # GOP-16 have 2 and 1 pairs), at least 2; DESIGN §7 has the expected critical paths

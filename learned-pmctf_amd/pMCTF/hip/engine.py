@@ -953,16 +953,21 @@ class HipEngine:
 
     # ------------------------------------------------------------------ a8 compress_one_stage (pMCTF_L.py:398-420)
     def compress_one_stage(self, ref, cur, code_lt, mv_hat, ischroma, stage_idx=0, q_index=0, ar_order=False,
-                           on_stream=None, defer=False):
-        """on_stream(kind, SymbolStream): called as soon as a stream's symbols are complete (kind "H" / "L")"""
+                           on_stream=None, defer=False, code_h=True):
+        """on_stream(kind, SymbolStream): called as soon as a stream's symbols are complete (kind "H" / "L").
+        code_h=False: only the temporal lifting and the L coder (the H coder of this plane set runs elsewhere —
+        pmctf_dist's split of a pair over ranks; the four spatial coders of a pair are independent given mv_hat,
+        pMCTF_L.py:398-420,570-592)."""
         if ischroma:
             mv_hat = ops.bilinear_down2(mv_hat, 2.0)
         L_t, H_t, _, _ = self.forward_MCTF(ref, cur, mv_hat, stage_idx)
-        qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
-        H_syn, h_stream = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, ar_order, defer=True)
-        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "H_stream": h_stream, "L_t_hat": None, "L_stream": None}
-        if on_stream is not None:
-            on_stream("H", h_stream)
+        out = {"L_t": L_t, "H_t": H_t, "H_t_hat": None, "H_stream": None, "L_t_hat": None, "L_stream": None}
+        H_syn = None
+        if code_h:
+            qp_scale = get_curr_q(self.sd[f"hp_q_scale.{stage_idx}"], q_index)
+            H_syn, out["H_stream"] = self.pwave_compress("hp_coder", H_t, q_index, qp_scale, ar_order, defer=True)
+            if on_stream is not None:
+                on_stream("H", out["H_stream"])
         L_syn = None
         if code_lt:
             L_syn, out["L_stream"] = self.pwave_compress("lp_coder", L_t, q_index, None, ar_order, defer=True)
@@ -972,7 +977,8 @@ class HipEngine:
         def finish():
             """the reconstructions (synthesis transforms + post-processing), after every stream of the pair is with
             the range coder: its tail overlaps with this GPU work instead of leaving the GPU idle"""
-            out["H_t_hat"] = H_syn()
+            if H_syn is not None:
+                out["H_t_hat"] = H_syn()
             if L_syn is not None:
                 out["L_t_hat"] = L_syn()
             return out

@@ -506,6 +506,64 @@ class pMCTF(nn.Module):
                              me_downsample=me_downsample)
         return {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
 
+    # ---- a frame pair in PARTS (pmctf_dist: ranks that a temporal stage leaves idle share the pairs it has) ------------
+    # encode_one_stage's write branch = motion (SpyNet + motion codec -> mv_hat, {k}_mv.bin), then four spatial coder calls
+    # that are independent given mv_hat (pMCTF_L.py:398-420,570-592): H and L of luma, H and L of chroma.  The two methods
+    # below run those pieces on their own, through the same engine code (stream launches), so that the union of the
+    # parts of a pair — whichever ranks run them — is encode_one_stage's result: same files, bits and tensors
+    # (tests/test_gpu_engine.py::test_pair_parts_equal_encode_one_stage).
+    @torch.no_grad()
+    @_gated
+    def encode_pair_motion(self, ref_frame, cur_frame, dpb, output_path, stage_idx=0, q_index=0, me_downsample=1,
+                           on_dpb=None):
+        """Motion of one pair: writes {k}_mv.bin.  dpb / on_dpb as in encode_one_stage.  -> {mv_hat, dpb, bit_ME}"""
+        self._check_ds(me_downsample)
+        self.flush()
+        ref_frame, cur_frame = unwrap((list(ref_frame), list(cur_frame)))
+        eng = self.engine()
+        dev = ref_frame[0].device
+        c = lambda t: t.to(dev).contiguous()
+        mv = eng.compress_mv(c(ref_frame[0]), c(cur_frame[0]), dpb if callable(dpb) else unwrap(dpb), stage_idx=stage_idx,
+                             q_index=q_index, me_downsample=me_downsample)
+        job = eng.coder.submit(mv["stream"], eng.tables, lambda n: mv_header(n, 0), output_path.replace(".bin", "_mv.bin"),
+                               eng.keep_streams)
+        new = {"mv_feature": mv["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": mv["mv_y_hat"].permute(0, 3, 1, 2)}
+        if on_dpb is not None:
+            on_dpb(new)
+        return {"mv_hat": mv["mv_hat"], "dpb": new, "bit_ME": job.result()[0] * 8.0}
+
+    @torch.no_grad()
+    @_gated
+    def encode_pair_part(self, ref_planes, cur_planes, mv_hat, chroma, kinds, code_lt, output_path, pic_width, pic_height,
+                         stage_idx=0, q_index=0):
+        """The spatial coders `kinds` (a subset of ("H", "L"); "L" only where the stage codes L) of the luma (chroma=False:
+        planes (1,1,H,W)) or chroma (True: (2,1,H/2,W/2)) planes of one pair, given the pair's decoded motion field.
+        Writes the files encode_one_stage would ({k}.bin / {k}_C_main.bin, 0_main.bin / 0_C_main.bin).
+        -> {"H": reconstructed H planes or None, "L": the L planes this part is responsible for — coded and reconstructed
+        if "L" in kinds, the temporal low-pass itself where the stage does not code L, else None, "bits": {kind: bits}}"""
+        self.flush()
+        ref_planes, cur_planes, mv_hat = unwrap((ref_planes, cur_planes, mv_hat))
+        eng = self.engine()
+        dev = ref_planes.device
+        c = lambda t: t.to(dev).contiguous()
+        base = osp.basename(output_path)
+        if chroma:
+            paths = {"H": output_path.replace(".bin", "_C_main.bin"), "L": output_path.replace(base, "0_C_main.bin")}
+            header = lambda n: image_header(pic_height // 2, pic_width // 2, 2, n)
+        else:
+            paths = {"H": output_path, "L": output_path.replace(base, "0_main.bin")}
+            header = lambda n: image_header(pic_height, pic_width, 1, n)
+        assert set(kinds) <= {"H", "L"} and ("L" not in kinds or code_lt)
+        jobs = {}
+
+        def submit(kind, stream):
+            jobs[kind] = eng.coder.submit(stream, eng.tables, header, paths[kind], eng.keep_streams)
+        out = eng.compress_one_stage(c(ref_planes), c(cur_planes), bool(code_lt) and "L" in kinds, c(mv_hat), bool(chroma),
+                                     stage_idx, q_index, False, on_stream=submit, defer=True, code_h="H" in kinds)
+        out["finish"]()
+        low = out["L_t_hat"] if "L" in kinds else (out["L_t"] if not code_lt else None)
+        return {"H": out["H_t_hat"], "L": low, "bits": {k: j.result()[0] * 8.0 for k, j in jobs.items()}}
+
     @torch.no_grad()
     @_gated
     def forward_one_stage(self, ref_frame, cur_frame, q_index, code_lt, dpb, mv_hat=None, stage_idx=0, me_downsample=1):

@@ -58,37 +58,52 @@ def _is_nccl(dist):
 
 
 class _Relay:
-    """Hands the motion codec's context from the owner of pair k-1 to the owner of pair k (point-to-point).  The two
-    receive buffers are allocated once: a rank consumes a context (the motion codec copies it into its own storage)
-    before it asks for the next one."""
+    """Hands the motion codec's context from the owner of pair k-1 to the owner of pair k (point-to-point): ONE message
+    per hop — both tensors (mv_feature, ref_mv_y; channels-last storage) travel in one contiguous buffer.  A receive
+    buffer and a send buffer are allocated once.  Aliasing contract: what recv() returns are VIEWS of the receive
+    buffer, valid until this rank's next recv(); the motion codec consumes the context (copies it into its own
+    storage, in stream order) before the rank asks for the next one.  Send buffers come from a small pool that grows to
+    the number of sends a rank ever has in flight (a send never waits for an earlier one: no new wait edges between the
+    chains of GOPs in flight) and is reused from then on."""
 
     def __init__(self, dist, rank, world, device, shapes):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
         self.shapes = shapes                     # logical NCHW shapes of (mv_feature, ref_mv_y)
-        self.pending = []
+        self.pool = []                           # [send buffer, its last isend or None]
         self.comm_dev = device if _is_nccl(dist) else "cpu"
-        self.bufs = [torch.empty((n, h, w, c), dtype=torch.float32, device=self.comm_dev)      # channels-last storage
-                     for (n, c, h, w) in shapes]
+        self.numel = [n * c * h * w for (n, c, h, w) in shapes]
+        total = sum(self.numel)
+        self.rbuf = torch.empty(total, dtype=torch.float32, device=self.comm_dev)
         self.hops = 0
-        self.bytes_per_hop = sum(4 * b.numel() for b in self.bufs)
+        self.bytes_per_hop = 4 * total
+
+    def _views(self, buf):
+        out, o = {}, 0
+        for key, (n, c, h, w), cnt in zip(("mv_feature", "ref_mv_y"), self.shapes, self.numel):
+            out[key] = buf[o:o + cnt].view(n, h, w, c)
+            o += cnt
+        return out
 
     def recv(self, src):
-        out = {}
-        for key, buf in zip(("mv_feature", "ref_mv_y"), self.bufs):
-            self.dist.recv(buf, src=src)
-            out[key] = buf.to(self.device).permute(0, 3, 1, 2)
-        return out
+        self.dist.recv(self.rbuf, src=src)
+        local = self.rbuf if self.rbuf.device == torch.device(self.device) else self.rbuf.to(self.device)
+        return {k: v.permute(0, 3, 1, 2) for k, v in self._views(local).items()}
 
     def send(self, dpb, dst):
         self.hops += 1
-        for key in ("mv_feature", "ref_mv_y"):
-            t = dpb[key].permute(0, 2, 3, 1).contiguous().to(self.comm_dev)
-            self.pending.append((self.dist.isend(t, dst=dst), t))
+        slot = next((s for s in self.pool if s[1] is None or s[1].is_completed()), None)
+        if slot is None:
+            slot = [torch.empty(sum(self.numel), dtype=torch.float32, device=self.comm_dev), None]
+            self.pool.append(slot)
+        for key, v in self._views(slot[0]).items():
+            v.copy_(dpb[key].permute(0, 2, 3, 1))
+        slot[1] = self.dist.isend(slot[0], dst=dst)
 
     def drain(self):
-        for work, _ in self.pending:
-            work.wait()
-        self.pending = []
+        for slot in self.pool:
+            if slot[1] is not None:
+                slot[1].wait()
+                slot[1] = None
 
 
 def _record_layout(shapes):
@@ -117,6 +132,18 @@ class PairShardWorkspace:
         if t is None or tuple(t.shape) != tuple(shape) or t.device != torch.device(device):
             t = self.bufs[key] = torch.empty(shape, dtype=torch.uint8, device=device)
         return t
+
+
+def pair_parts(code_lt, group):
+    """How one pair is cut when `group` ranks share it (a stage with fewer pairs than ranks): a list of
+    (planes, kinds, offset) — planes "Y" (luma) or "C" (chroma), kinds the spatial coders of those planes this part runs,
+    offset the rank inside the group (0 = the pair's owner, which also estimates and codes the motion).  The four coder
+    calls of a pair are independent given mv_hat (pMCTF_L.py:398-420,570-592): luma / chroma on two ranks, and in the
+    stage that codes L the H and L coders of each on two more."""
+    if group >= 4 and code_lt:
+        return [("Y", ("H",), 0), ("Y", ("L",), 1), ("C", ("H",), 2), ("C", ("L",), 3)]
+    kinds = ("H", "L") if code_lt else ("H",)
+    return [("Y", kinds, 0), ("C", kinds, 1)]
 
 
 def encode_gop_pair_sharded(codec, frames, pic_height, pic_width, q_index, bin_folder, rank=0, world=1, dist=None,
@@ -172,6 +199,12 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
         step = 2 ** stage_idx
         code_lt = (stage_idx + 1) == stages
         me_num = min(codec.num_me_stages - 1, stage_idx)
+        if multi and G == 1 and world // num_frames >= 2 and hasattr(codec, "encode_pair_part"):
+            # fewer pairs than ranks: the ranks the stage would leave idle take PARTS of its pairs
+            _encode_stage_split(codec, gops[0], outs[0], stage_idx, num_frames, code_lt, me_num, pic_height, pic_width,
+                                q_index, bin_folders[0], psize, rank, world, dist, relay, ws, shapes, offs, rec_bytes,
+                                comm_dev, device, gather_bytes)
+            continue
         slots = (num_frames + world - 1) // world
         mine = [ws.get(("mine", j, stage_idx), (slots, rec_bytes), device) for j in range(G)]
         last_dpb = [{"mv_feature": None, "ref_mv_y": None} for _ in range(G)]
@@ -214,7 +247,18 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
         # ---- the one collective per GOP of the stage (same order on every rank)
         for j in range(G):
             o = outs[j]
-            if multi:
+            if multi and num_frames < world:
+                # fewer live records than ranks (several GOPs in flight, or a codec without the part API): every record
+                # is broadcast by its owner — the all-gather below would move world x slots records for num_frames live ones
+                everything = ws.get(("all", j, stage_idx), (world, slots, rec_bytes), comm_dev)
+                for p in range(num_frames):
+                    own = pair_owner(p, world, j, G)
+                    if own == rank:
+                        everything[own, 0].copy_(mine[j][0])
+                    dist.broadcast(everything[own, 0], src=own)
+                everything = everything.to(device)
+                gather_bytes.append(num_frames * rec_bytes)
+            elif multi:
                 everything = ws.get(("all", j, stage_idx), (world, slots, rec_bytes), comm_dev)
                 if _is_nccl(dist):
                     dist.all_gather_into_tensor(everything.view(-1), mine[j].view(-1))
@@ -245,3 +289,97 @@ def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_in
         stats["relay_hops"] = relay.hops if relay is not None else 0
         stats["relay_bytes_per_hop"] = relay.bytes_per_hop if relay is not None else 0
     return outs
+
+
+def _encode_stage_split(codec, frames, out, stage_idx, num_frames, code_lt, me_num, pic_height, pic_width, q_index,
+                        bin_folder, psize, rank, world, dist, relay, ws, shapes, offs, rec_bytes, comm_dev, device,
+                        gather_bytes):
+    """One temporal stage of ONE GOP with fewer pairs than ranks: pair p belongs to the group of `world // num_frames`
+    ranks starting at p * group.  The group's first rank (the owner) estimates and codes the motion — the motion context
+    still travels owner to owner — and hands mv_hat to the others; every part (pair_parts) runs forward_MCTF for its planes
+    and its spatial coder(s) and writes its files.  The subband tree is reassembled by one broadcast per produced tensor
+    (only live data moves: 5 x H x W floats per pair in total, as in the all-gather record) and one all-reduce of the bit
+    counts.  Results are those of encode_one_stage per pair."""
+    import os
+    group = world // num_frames
+    step = 2 ** stage_idx
+    parts = pair_parts(code_lt, group)
+    nccl = _is_nccl(dist)
+    recs = ws.get(("split", stage_idx), (num_frames, rec_bytes), comm_dev)
+    views = lambda p: [recs[p, o_:o_ + 4 * n].view(torch.float32).view(shp) for (o_, n), shp in zip(offs, shapes)]
+    bits = torch.zeros(num_frames, 5, dtype=torch.float64)                # H luma, H chroma, motion, L luma, L chroma
+    to_comm = lambda t: t if t.device == torch.device(comm_dev) else t.to(comm_dev)
+    pending = []
+    my_parts = [(p, part) for p in range(num_frames) for part in parts if p * group + part[2] == rank]
+    for p, (planes, kinds, off) in my_parts:
+        owner = p * group
+        i_ref = p * 2 * step
+        i_cur = i_ref + step
+        ref = frames[i_ref] if stage_idx == 0 else out["frames_coded"][i_ref][:2]
+        cur = frames[i_cur] if stage_idx == 0 else out["frames_coded"][i_cur][:2]
+        path = os.path.join(bin_folder, f"{i_cur}.bin")
+        L_t, L_tc, H_t, H_tc, mv_rec = views(p)
+        if off == 0:
+            dpb_in = {"mv_feature": None, "ref_mv_y": None} if p == 0 else (lambda src=owner - group: relay.recv(src))
+
+            def on_dpb(d, p=p):
+                if p + 1 < num_frames:
+                    relay.send(d, (p + 1) * group)
+            m = codec.encode_pair_motion([ref[0], ref[1]], [cur[0], cur[1]], dpb_in, path, stage_idx=me_num, q_index=q_index,
+                                         on_dpb=on_dpb)
+            mv_hat = m["mv_hat"]
+            mv_rec.copy_(mv_hat)
+            bits[p, 2] = float(m["bit_ME"])
+            for other in sorted({o for _, _, o in parts if o != 0}):
+                pending.append(dist.isend(mv_rec if nccl else mv_rec.contiguous(), dst=owner + other))
+            out["results"].append({"pair": p, "part": "motion", "dpb": m["dpb"]})
+        else:
+            dist.recv(mv_rec, src=owner)
+            mv_hat = mv_rec.to(device)
+        chroma = planes == "C"
+        r = codec.encode_pair_part(ref[1] if chroma else ref[0], cur[1] if chroma else cur[0], mv_hat, chroma, kinds,
+                                   code_lt, path, pic_width, pic_height, stage_idx=me_num, q_index=q_index)
+        if r["H"] is not None:
+            (H_tc if chroma else H_t).copy_(r["H"])
+            bits[p, 1 if chroma else 0] = float(r["bits"]["H"])
+        if r["L"] is not None:
+            (L_tc if chroma else L_t).copy_(r["L"])
+            if "L" in kinds:
+                bits[p, 4 if chroma else 3] = float(r["bits"]["L"])
+        out["results"].append({"pair": p, "part": planes + "".join(kinds)})
+    for w in pending:
+        w.wait()
+    if relay is not None:
+        relay.drain()
+    # ---- reassemble: who produced what (the same table on every rank), one broadcast per tensor, live data only
+    moved = 0
+    for p in range(num_frames):
+        owner = p * group
+        producer = {"mv": owner}
+        for planes, kinds, off in parts:
+            c = planes == "C"
+            if "H" in kinds:
+                producer["Hc" if c else "H"] = owner + off
+            if "L" in kinds or not code_lt:
+                producer["Lc" if c else "L"] = owner + off
+        for name, t in zip(("L", "Lc", "H", "Hc", "mv"), views(p)):
+            dist.broadcast(t, src=producer[name])
+            moved += 4 * t.numel()
+    bits_c = bits.to(comm_dev) if nccl else bits
+    dist.all_reduce(bits_c, op=dist.ReduceOp.SUM)
+    bits = bits_c.cpu()
+    gather_bytes.append(moved)
+    local = recs if recs.device == torch.device(device) else recs.to(device)
+    for p in range(num_frames):
+        i_ref = p * 2 * step
+        i_cur = i_ref + step
+        L_t, L_tc, H_t, H_tc, mv_hat = [local[p, o_:o_ + 4 * n].view(torch.float32).view(shp)
+                                        for (o_, n), shp in zip(offs, shapes)]
+        out["frames_coded"][i_ref] = [L_t, L_tc, None]
+        out["frames_coded"][i_cur] = [H_t, H_tc, mv_hat]
+        b = bits[p].tolist()
+        out["bits"][i_cur] = b[0] + b[1] + b[2]
+        out["bits_mv"][i_cur] = b[2]
+        if code_lt:
+            out["bits"][i_ref] = b[3] + b[4]
+            out["bits_mv"][i_ref] = 0.0

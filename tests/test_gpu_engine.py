@@ -1113,6 +1113,48 @@ def _pair_shard_gpu_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_pair_parts_equal_encode_one_stage(setup):
+    """pmctf_dist lets the ranks a temporal stage leaves idle take PARTS of its pairs: the motion, and the four spatial
+    coder calls that are independent given mv_hat (pMCTF_L.py:398-420,570-592).  encode_pair_motion + encode_pair_part for
+    (luma, chroma) x (H, L), each on its own, must write encode_one_stage's files and return its tensors and bit counts —
+    for a pair that codes L (all four parts, and the two-part cut) and for one that does not."""
+    net, _ = setup
+    fr = frames(W, H, 2, device="cuda", seed=53)
+    for code_lt in (True, False):
+        with tempfile.TemporaryDirectory() as td:
+            ref = net.encode_one_stage(ref_frame=fr[0], cur_frame=fr[1], output_path=os.path.join(td, "1.bin"), pic_height=H,
+                                       pic_width=W, stage_idx=0, code_lt=code_lt, psize=128, skip_decoding=True,
+                                       dpb={"mv_feature": None, "ref_mv_y": None}, q_index=3)
+            files_ref = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+        for cut in ((("H",), ("L",)) if code_lt else (("H",),), (("H", "L"),) if code_lt else (("H",),)):
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "1.bin")
+                m = net.encode_pair_motion(fr[0], fr[1], {"mv_feature": None, "ref_mv_y": None}, path, stage_idx=0, q_index=3)
+                assert_same(m["mv_hat"], ref["mv_hat"], "mv_hat")
+                assert m["bit_ME"] == ref["bit_ME"]
+                for k in ("mv_feature", "ref_mv_y"):
+                    assert_same(m["dpb"][k], ref["dpb"][k], k)
+                got = {}
+                for chroma in (False, True):
+                    for kinds in cut:
+                        r = net.encode_pair_part(fr[0][1 if chroma else 0], fr[1][1 if chroma else 0], m["mv_hat"], chroma,
+                                                 kinds, code_lt, path, W, H, stage_idx=0, q_index=3)
+                        for k in ("H", "L"):
+                            if r[k] is not None:
+                                got[k + ("c" if chroma else "")] = r[k]
+                        for k, b in r["bits"].items():
+                            got["bits_" + k + ("c" if chroma else "")] = b
+                files = {n: open(os.path.join(td, n), "rb").read() for n in sorted(os.listdir(td))}
+            assert files == files_ref
+            assert_same(got["H"], ref["H_t"], "H_t")
+            assert_same(got["Hc"], ref["H_tc"], "H_tc")
+            assert_same(got["L"], ref["L_t"], "L_t")
+            assert_same(got["Lc"], ref["L_tc"], "L_tc")
+            assert got["bits_H"] + got["bits_Hc"] == ref["bit_H"]
+            if code_lt:
+                assert got["bits_L"] + got["bits_Lc"] == ref["bit_L"] and got["bits_Lc"] == ref["bit_Lc"]
+
+
 def test_pair_sharding_two_ranks_real_codec(cuda):
     """BASELINE configs[4] on what one box allows: two fresh processes share the GPU (gloo carries the relay and the
     gather; on the 8-GPU node the same code runs over RCCL), GOP 8 at 128x128 with four ME stages and the REAL codec.
@@ -1135,7 +1177,9 @@ def test_pair_sharding_two_ranks_real_codec(cuda):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert sorted(r[4] for r in res) == [3, 4]             # 4+2+1 pairs: rank 0 codes 2+1+1, rank 1 codes 2+1
+    # 4+2+1 pairs: 2+1 whole pairs per rank; the last pair (the one that codes L) is split: motion + luma coders on rank 0,
+    # chroma coders on rank 1 (pmctf_dist.pair_parts)
+    assert sorted(r[4] for r in res) == [4, 5]
     for rank, bits, bits_mv, fc, _, o1, o2 in res:
         for (b_, bm_, fc_, _), want in (((bits, bits_mv, fc, None), ref), (o1, ref), (o2, ref2)):
             assert b_ == want["bits"] and bm_ == want["bits_mv"], rank
@@ -1189,7 +1233,8 @@ def test_pair_sharding_two_ranks_1080p_gop16_vs_reference(cuda):
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    assert sorted(r[5] for r in res) == [7, 8]                 # 8+4+2+1 pairs: rank 0 codes 4+2+1+1, rank 1 codes 4+2+1
+    # 8+4+2+1 pairs: 4+2+1 whole pairs per rank, the last pair split (motion + luma coders / chroma coders)
+    assert sorted(r[5] for r in res) == [8, 9]
     assert res[0][4] == res[1][4]                              # the same subband tree on both ranks
     for rank, bits, bits_mv, ps, _, _, files, stats in res:
         assert bits == g["gop.bits"].tolist() and bits_mv == g["gop.bits_mv"].tolist(), rank

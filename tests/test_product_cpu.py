@@ -299,6 +299,28 @@ class _ChainCodec:
                 "mv_hat": torch.full((1, 2) + tuple(ry.shape[2:]), v), "dpb": new,
                 "bit_H": 1000.0 + round(v * 1e6), "bit_ME": 10.0 + stage_idx, "bit_L": 77.0 if code_lt else None}
 
+    # the pair in parts (pmctf_dist's split of a pair over the ranks a stage leaves idle): same numbers, piecewise
+    def encode_pair_motion(self, ref_frame, cur_frame, dpb, output_path, stage_idx=0, q_index=0, me_downsample=1,
+                           on_dpb=None):
+        if callable(dpb):
+            dpb = dpb()
+        new, v = self._chain(ref_frame, cur_frame, dpb, stage_idx, q_index)
+        if on_dpb is not None:
+            on_dpb(new)
+        return {"mv_hat": torch.full((1, 2) + tuple(ref_frame[0].shape[2:]), v), "dpb": new, "bit_ME": 10.0 + stage_idx}
+
+    def encode_pair_part(self, ref_planes, cur_planes, mv_hat, chroma, kinds, code_lt, output_path, pic_width, pic_height,
+                         stage_idx=0, q_index=0):
+        v = float(mv_hat.reshape(-1)[0])
+        low = (ref_planes + cur_planes) / 2 + (-v if chroma else v)
+        high = cur_planes - ref_planes + (2 * v if chroma else v)
+        bits = {}
+        if "H" in kinds:
+            bits["H"] = 400.0 if chroma else 600.0 + round(v * 1e6)
+        if "L" in kinds:
+            bits["L"] = 27.0 if chroma else 50.0
+        return {"H": high if "H" in kinds else None, "L": low if ("L" in kinds or not code_lt) else None, "bits": bits}
+
 
 def _pair_worker(rank, world, port, q):
     import torch.distributed as dist
@@ -308,13 +330,18 @@ def _pair_worker(rank, world, port, q):
     frames = [[torch.rand(1, 1, 8, 12, generator=g), torch.rand(2, 1, 4, 6, generator=g)] for _ in range(16)]
     with tempfile.TemporaryDirectory() as td:
         enc = pmctf_dist.encode_gop_pair_sharded(_ChainCodec(), frames, 8, 12, 3, td, rank, world, dist)
+    stats = {}
+    with tempfile.TemporaryDirectory() as td:       # a second GOP through the same call: results must not depend on history
+        enc2 = pmctf_dist.encode_gop_pair_sharded(_ChainCodec(), frames, 8, 12, 3, td, rank, world, dist, stats=stats)
+    assert enc2["bits"] == enc["bits"]
+    work = [(r.get("pair"), r.get("part")) if "part" in r else ("whole",) for r in enc["results"]]
     q.put((rank, enc["bits"], enc["bits_mv"], [[t if t is None else t.numpy() for t in fc] for fc in enc["frames_coded"]],
-           len(enc["results"])))
+           work, stats))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_pair_sharding_inside_a_gop_gloo(world):
     """BASELINE configs[4] layout: the pairs of every temporal stage spread over the ranks, the motion context relayed
     from pair to pair (send/recv), one all-gather of fixed-size pair records per stage.
@@ -328,15 +355,33 @@ def test_pair_sharding_inside_a_gop_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() + world) % 2000
+    import pmctf_dist
     procs = [ctx.Process(target=_pair_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert sum(r[4] for r in res) == 15                       # 8 + 4 + 2 + 1 pairs, each coded exactly once
-    for rank, bits, bits_mv, fc, _ in res:
+    # every pair coded exactly once: as a whole by one rank, or — in the stages with at most half as many pairs as ranks —
+    # as one motion part plus the parts of pmctf_dist.pair_parts spread over the pair's group of ranks
+    whole = sum(sum(1 for w in r[4] if w == ("whole",)) for r in res)
+    split_stages = [n for n in (8, 4, 2, 1) if world // n >= 2]
+    assert whole == sum(n for n in (8, 4, 2, 1) if world // n < 2)
+    parts = sorted(w for r in res for w in r[4] if w != ("whole",))
+    expect = []
+    for n in split_stages:
+        for p in range(n):
+            expect.append((p, "motion"))
+            expect += [(p, pl + "".join(k)) for pl, k, _ in pmctf_dist.pair_parts(n == 1, world // n)]
+    assert parts == sorted(expect)
+    if world == 8:      # the last stage: H and L coders of luma and of chroma on four ranks
+        who = {w[1]: r[0] for r in res for w in r[4] if w != ("whole",) and w[1] in ("YL", "CL")}
+        assert who == {"YL": 1, "CL": 3}            # the L coders run beside the H coders (ranks 0 and 2), not after them
+        # only live data moves: per stage exactly (pairs of the stage) x (record of one pair)
+        rec = 4 * (2 * 8 * 12 + 2 * 2 * 4 * 6 + 2 * 8 * 12)
+        assert all(abs(b - n * rec) <= 64 * n for b, n in zip(res[0][5]["gather_bytes_per_stage"], (8, 4, 2, 1)))
+    for rank, bits, bits_mv, fc, _, _ in res:
         assert bits == ref["bits"] and bits_mv == ref["bits_mv"], rank
         for a, b in zip(fc, ref["frames_coded"]):
             for x, y in zip(a, b):
