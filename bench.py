@@ -336,7 +336,7 @@ def main():
             out["parity_sweep"] = parity_sweep()
         del rec
         traffic = None      # HBM bytes per plane of this kernel from the committed rocprofv3 --pmc passes (profiles/)
-        for name in ("round3_dominant_kernel.json", "round2_dominant_kernel.json", "round1_dominant_kernel.json"):
+        for name in ("round4_dominant_kernel.json", "round3_dominant_kernel.json", "round2_dominant_kernel.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["traffic_bytes_per_launch"]

@@ -39,7 +39,6 @@ with torch.no_grad():
     r = eng.motion_code(mv, dpb, 0, 3)                 # first pair of a GOP: no context
     ctx = {"mv_feature": r["mv_feature"].permute(0, 3, 1, 2), "ref_mv_y": r["mv_y_hat"].permute(0, 3, 1, 2)}
     torch.cuda.synchronize()
-    import subprocess
     for _ in range(4):                      # four identical chained calls: the report takes the last quarter of the launches
         eng.motion_code(mv, ctx, 0, 3)
         torch.cuda.synchronize()

@@ -1,6 +1,11 @@
 # rocprofv3 counter passes that say where the waves of ONE kernel spend their cycles (issue / wait / LDS / VMEM), one
-# group per pass.  usage: pmc_stalls.sh <tag> <kernel-name regex> <program> [args...]   (run on the GPU box)
+# group per pass.  usage: pmc_stalls.sh <tag> <kernel-name regex> <script.py> [args...]   (run on the GPU box)
+# The profiled program is ALWAYS `python3 <script.py> ...`, started by rocprofv3 itself: with --pmc the profiler's preloaded
+# library initialises the GPU before the program starts, so any hop after `--` that re-executes (env, bash -c, a
+# `#!/usr/bin/env` script, a launcher) is an exec from a process that holds the GPU — which this pool forbids.
 tag=$1; shift; pat=$1; shift
+case "$1" in *.py) ;; *) echo "usage: $0 <tag> <kernel regex> <script.py> [args...] (the script runs under python3)"; exit 2;; esac
+script=$(realpath "$1"); shift; set -- "$script" "$@"     # the passes run from /tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc/$tag
 mkdir -p $out
@@ -13,7 +18,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WA
            "SQ_WAVES SQ_INSTS_VMEM_RD"; do
   g=$(echo $grp | tr ' ' '_')
   rm -rf /tmp/pmc_$g
-  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$g -- "$@" > $out/$g.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc_$g -- python3 "$@" > $out/$g.log 2>&1
   f=$(find /tmp/pmc_$g -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then (head -1 $f; grep -E "$pat" $f) > $out/pmc_$g.csv; else echo "no csv for $g"; tail -2 $out/$g.log; fi
   rm -rf /tmp/pmc_$g
