@@ -36,9 +36,14 @@ def gather_gop_metrics(local, n_gops, gop, dist=None, device="cpu"):
 #     rank(k-1), runs the motion codec (0.33 TFLOP, ~8 ms on an MI355X), sends it on to rank(k+1) the moment it exists
 #     and only then codes the rest of its pair.  Critical path per stage: (pairs-1) hops of (motion codec + 37 MB over
 #     one xGMI link) ~ 8-9 ms each; the other 93 % of a pair's work runs concurrently on all ranks.
-#   * ONE collective per stage: an all-gather of one fixed-size byte record per pair — L, L chroma, H, H chroma, the
-#     motion field (5 * H * W floats = 44 MB at 1080p) and three bit counts as float64 — into a buffer allocated once per
-#     stage; `frames_coded` holds views of it (no second copy).  Every rank ends with the complete subband tree.
+#   * ONE collective per stage while it has at least as many pairs as ranks: an all-gather of one fixed-size byte record
+#     per pair — L, L chroma, H, H chroma, the motion field (5 * H * W floats = 44 MB at 1080p) and three bit counts as
+#     float64 — into a buffer allocated once per stage; `frames_coded` holds views of it (no second copy).  Every rank
+#     ends with the complete subband tree.
+#   * A stage with at most half as many pairs as ranks (the late stages: 4, 2, 1 pairs) is shared in PARTS: the four spatial
+#     coder calls of a pair are independent given mv_hat, so the ranks the stage would leave idle take the chroma coders
+#     (and, in the stage that codes L, the L coders) of its pairs; the tree is then reassembled by broadcasts of exactly
+#     the tensors that were produced (pair_parts, _encode_stage_split).
 #
 # Results are identical to pmctf_gop.encode_gop on one device.  On the GPU node the backend is "nccl" (= RCCL over xGMI:
 # device tensors, all_gather_into_tensor); under "gloo" (CPU tests, one-GPU rehearsal) records are staged through host
@@ -163,8 +168,9 @@ def encode_gop_pair_sharded(codec, frames, pic_height, pic_width, q_index, bin_f
 def encode_gops_pair_sharded_overlapped(codec, gops, pic_height, pic_width, q_index, bin_folders, rank=0, world=1,
                                         dist=None, psize=128, stats=None, workspace=None):
     """Several closed GOPs in flight over the same ranks (SURVEY 8e's GOP overlap): stage s of ALL of them is coded before
-    stage s+1 of any, the chains of consecutive GOPs run in opposite directions (pair_owner), so the ranks one GOP leaves
-    idle in its late stages (4, 2, 1 pairs) code the other's.  With 8 ranks and two GOP-16s the critical path is
+    stage s+1 of any, and the chains of the GOPs start on DIFFERENT ranks but all run in the same direction, rank r to rank
+    r+1 (pair_owner: one direction is what keeps the chains deadlock-free under RCCL), so the ranks one GOP leaves idle
+    in its late stages (4, 2, 1 pairs) code the other's.  With 8 ranks and two GOP-16s the critical path is
     2 + 1 + 1 + 1 pair-times for 32 frames instead of 2 x 4.  Per GOP-stage: one relay chain and ONE all-gather, exactly as
     in encode_gop_pair_sharded; a rank works through its pairs of a stage in the order of their position in their chain
     (lowest first: every wait is for a pair with a lower position, so the chains cannot deadlock, and the sends r -> r+1 of
