@@ -506,8 +506,12 @@ _Pragma("unroll")
 // alternate without copies, one copy per 16-channel chunk remains), every LDS address is ONE per-wave base register plus an
 // immediate, the staging slots' global offsets and bounds are computed once per tile, and the 16-channel chunk advances
 // a scalar base.  Same arithmetic and sum order as every other variant (chunk, ky, kx, ci ascending).
-template <int MT, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(ConvArgs a) {
+// BSUM: summation rule "blocks" (per-chunk sums from zero, added in turn to a second accumulator set).  Two sets of
+// MT x 4 quads do not fit 256 registers at MT = 7: that instantiation runs ONE workgroup per CU (512 registers per lane, the
+// compiler keeps one set in AGPRs); the rule-0 instantiation measured the same 137 TFLOP/s at one workgroup per CU
+// (docs/history.md section 9), i.e. the kernel is MFMA-bound, not occupancy-bound.
+template <int MT, int NBUF, bool BSUM = false>
+__global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)) void conv3x3s1_wave_kernel(ConvArgs a) {
     constexpr int NT = 4, LH = 6, LW = 18, MAXP = 7;
     constexpr int BUFSZ = LH * LW * CP;
     constexpr int E = LH * LW * 4;
@@ -526,11 +530,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
     float *wlds = lds + wave * NBUF * BUFSZ;
 
     f32x4 acc[MT][NT];
+    f32x4 tot[BSUM ? MT : 1][BSUM ? NT : 1];
     {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = BSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
         }
@@ -637,9 +642,27 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv3x3s1_wave_kernel(
         // nine taps: the next chunk's first fragments arrived in set 1
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
+        if constexpr (BSUM) {       // the chunk's sums are complete: (S_0 + bias), + S_1, ...
+            const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    tot[mt][nt] = cb == 0 ? acc[mt][nt] + b : tot[mt][nt] + acc[mt][nt];
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
         // the other buffer was last read in chunk cb-1 by this same wave (NBUF = 1: this buffer, all of whose reads have
         // been issued by now): in-order LDS makes the overwrite safe
         if (more) stash(NBUF == 2 ? ((cb + 1) & 1) : 0);
+    }
+    if constexpr (BSUM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
     }
 
     PM_EPILOGUE_NOTRANS(a,
@@ -1565,6 +1588,17 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
                 static std::once_flag once_7b;
                 allow_big_lds(conv7x7s1_pipe_kernel<MT, NT, true>, once_7b);
                 CONV_LAUNCH((conv7x7s1_pipe_kernel<MT, NT, true>), grid, dim3(256), 2 * smem, st, b);
+                return pm_launch_status();
+            }
+        }
+        if constexpr (NT == 4 && TW16 == 2 && (MT == 4 || MT == 7)) {
+            if (sc.bchunks == 1 && !sc.bias_first && a.act <= pm::ACT_LEAKY && a.KH == 3 && a.KW == 3 && a.S == 1 &&
+                wave_eligible(a) && knob("K33") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+                const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
+                const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+                static std::once_flag once_kb;
+                allow_big_lds(conv3x3s1_wave_kernel<MT, 2, true>, once_kb);
+                CONV_LAUNCH((conv3x3s1_wave_kernel<MT, 2, true>), grid, dim3(256), wsmem, st, b);
                 return pm_launch_status();
             }
         }

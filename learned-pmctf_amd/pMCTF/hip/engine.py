@@ -329,14 +329,16 @@ class HipEngine:
     def sum_rule(cls, p, weight, stride=1):
         """Summation rule of the convolution with parameter key p (include/pmctf_hip.h PMCTF_SUM_*).
         KH*KW > 1 layers of the SIGNAL path — motion estimation, motion codec, temporal lifting, the spatial lifting DWT
-        and its inverse: everything a coefficient value or the motion field is computed by — add their products the way
+        and its inverse: everything a coefficient value or the motion field is computed by — and of the post-processing
+        CNN (64 channels: the rule costs its kernels nothing, and it is what the reconstruction's PSNR sees) add their
+        products the way
         ATen's CPU convolution does (per 16-channel block from zero, block sums in turn, bias after the first): measured,
         the last bits of exactly these layers decide the symbols that differed from the reference's
         (profiles/round4_flip_attribution.md).  The entropy-parameter networks, post-processing, every 1x1 and depthwise
         layer of those networks keep the single chain from the bias; so do the depthwise and the 1x1 layers of the signal
         path, for which the chain IS ATen's order — except where ATen blocks a 1x1 layer's reduction (aten_rules)."""
         cout, cin, kh, kw = (int(v) for v in weight.shape)
-        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return ops.SUM_CHAIN
         if kh * kw > 1:
             return ops.SUM_BLOCKS

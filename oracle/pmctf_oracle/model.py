@@ -89,7 +89,7 @@ class Oracle:
         shape-dependent exception, also ATen's: a lifting step's 3x1 filter whose (reflect-padded) input is ONE plane of
         at most 20 480 elements does not go through oneDNN (Convolution.cpp `use_mkldnn`) but through im2col + gemv,
         which starts from the bias — rule 0."""
-        if groups != 1 or not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p):
+        if groups != 1 or not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return 0
         if w.size(2) * w.size(3) == 1:
             # 1x1 layers: one chain from the bias, unless ATen's jit_1x1 kernel blocks the reduction (aten_rules: B channels)
