@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include "pm_tanh_tables.h"
 #include "pm_log_tables.h"
+#define PM_SLEEF_FN __device__ __forceinline__
+#include "pm_sleef_f32.h"
 
 namespace pm {
 
@@ -82,7 +84,8 @@ __device__ __forceinline__ void tanh_rows_to_lds(uint4 *dst, int tid, int nthrea
     for (int i = tid; i < TANH_LDS_UINT4; i += nthreads) dst[i] = src[i];
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf_(-x)); }
+// torch.sigmoid of a float CPU tensor: 1 / (1 + Sleef_expf16_u10(0 - x)), transcribed in pm_sleef_f32.h
+__device__ __forceinline__ float sigmoidf_(float x) { return pm_aten_sigmoidf(x); }
 
 // natural log: the schedule of Intel MKL's vmsLn (high accuracy, AVX-512 kernel) = torch.log on a float32 CPU tensor, bit
 // for bit on [2^-100, 2^100) (oracle/c/pm_math.h pm_logf has the derivation; tools/mkl_log_tables.py --verify the check);

@@ -223,11 +223,14 @@ class CaptureGate:
 
 
 class HipEngine:
-    PRECISIONS = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
+    PRECISIONS = {"f32": 0, "f32-aten": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
 
     def __init__(self, state_dict, num_me_stages, device, gaussian_tables, bit_est_tables, decomp_levels=4,
                  coder_threads=4, precision="f32"):
-        """precision: "f32" = PM-F32, the product's arithmetic (bit-exact against the oracle).  "bf16x3" / "bf16x2" /
+        """precision: "f32" = PM-F32, the product's arithmetic (bit-exact against the oracle).  "f32-aten": PM-F32 with
+        ATen's summation order in EVERY layer, the entropy-parameter networks included (sum_rule): what the reference's
+        CPU path computes, to the bit, on frames whose planes ATen evaluates through oneDNN — the written files then equal
+        the reference's byte for byte and its files decode (a few percent slower: aten_all).  "bf16x3" / "bf16x2" /
         "bf16": the AUXILIARY reduced-precision profile — the dense 3x3 convolutions with 64 / 112 couts on planes of at
         least ops.SPLIT_MIN_PX pixels run on bf16 MFMA with operands split into 3 / 2 / 1 planes (conv_split.hip); every
         other kernel is unchanged.  Encoder and decoder built with the same profile agree bit for bit; results differ
@@ -236,6 +239,7 @@ class HipEngine:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self.precision = precision
         self.nsplit = self.PRECISIONS[precision]
+        self.aten_all = precision == "f32-aten"
         if not torch.cuda.is_available():
             raise RuntimeError("pMCTF HIP engine needs a GPU: the product path has no CPU fallback")
         _lib.hip()
@@ -325,27 +329,29 @@ class HipEngine:
     # ------------------------------------------------------------------ packed layers
     SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
 
-    @classmethod
-    def sum_rule(cls, p, weight, stride=1):
+    def sum_rule(self, p, weight, stride=1):
         """Summation rule of the convolution with parameter key p (include/pmctf_hip.h PMCTF_SUM_*).
         KH*KW > 1 layers of the SIGNAL path — motion estimation, motion codec, temporal lifting, the spatial lifting DWT
         and its inverse: everything a coefficient value or the motion field is computed by — and of the post-processing
         CNN (64 channels: the rule costs its kernels nothing, and it is what the reconstruction's PSNR sees) add their
-        products the way
-        ATen's CPU convolution does (per 16-channel block from zero, block sums in turn, bias after the first): measured,
-        the last bits of exactly these layers decide the symbols that differed from the reference's
-        (profiles/round4_flip_attribution.md).  The entropy-parameter networks, post-processing, every 1x1 and depthwise
-        layer of those networks keep the single chain from the bias; so do the depthwise and the 1x1 layers of the signal
-        path, for which the chain IS ATen's order — except where ATen blocks a 1x1 layer's reduction (aten_rules)."""
+        products the way ATen's CPU convolution does (per 16-channel block from zero, block sums in turn, bias after the
+        first): measured, the last bits of exactly these layers decide the symbols that differed from the reference's
+        (profiles/round4_flip_attribution.md).  1x1 layers follow the chain from the bias, which IS ATen's order — except
+        where ATen blocks a 1x1 layer's reduction or leaves oneDNN (aten_rules).
+        The entropy-parameter networks keep the single chain from the bias in the default profile (their last bits move
+        a CDF row now and then, not a coefficient: same sizes, a few files differ in bytes); with precision "f32-aten"
+        they follow ATen's order like the signal path."""
         cout, cin, kh, kw = (int(v) for v in weight.shape)
-        if not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
+        if not (self.aten_all or p.startswith(self.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return ops.SUM_CHAIN
         if kh * kw > 1:
             return ops.SUM_BLOCKS
-        if cin >= 112 and stride == 1:
+        if stride == 1 and (cin >= 112 or self.aten_all):
             # a 1x1 layer: ATen's jit_1x1 kernel cuts the reduction of wide layers into blocks on some plane sizes
-            # (e.g. 256 -> 64 at 576x960: blocks of 96 channels); the rule follows from the shape of the call
-            return lambda n, h, w: aten_rules.conv1x1_sum_rule(cin, cout, n, h, w)
+            # (e.g. 256 -> 64 at 576x960: blocks of 96 channels); the rule follows from the shape of the REFERENCE's call
+            # (its tensors hold one luma or two chroma planes, whatever batch this build has stacked)
+            tls = self._ref_tls
+            return lambda n, h, w: aten_rules.conv1x1_sum_rule(cin, cout, getattr(tls, "planes", None) or n, h, w)
         return ops.SUM_CHAIN
 
     @contextlib.contextmanager
@@ -775,7 +781,7 @@ class HipEngine:
                 tq = ops.empty_nhwc(N, H // 2, W // 2, t.shape[3], self.dev)
                 ew(EW_COPY, as_nchw(t)[:, :, py::2, px::2], out=as_nchw(tq))
                 tq = ops.conv_at_class(self.conv(q + ".conv2", 1, 1), o, step, res1=tq)
-                params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq)
+                params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq, rule_hw=(H, W))
             else:
                 t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
                 params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)
@@ -1130,7 +1136,7 @@ class HipEngine:
                     tq = ops.empty_nhwc(N, H // 2, W // 2, t.shape[3], self.dev)
                     ew(EW_COPY, as_nchw(t)[:, :, py::2, px::2], out=as_nchw(tq))
                     tq = ops.conv_at_class(self.conv(q + ".conv2", 1, 1), o, step, res1=tq)
-                    params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq)
+                    params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(tq, rule_hw=(H, W))
                 else:
                     t = self.context_residual(f"{p}.y_spatial_prior_{step}_out.1", t)
                     params = self.conv(f"{p}.y_spatial_prior_{step}_out.2")(t)

@@ -131,7 +131,9 @@ class Conv2d:
         Wo = (W + 2 * self.pad[1] - self.KW) // self.stride + 1
         return (N, Ho, Wo, self.Cout)
 
-    def __call__(self, x, act=ACT_NONE, slope=0.0, res1=None, res2=None, out=None):
+    def __call__(self, x, act=ACT_NONE, slope=0.0, res1=None, res2=None, out=None, rule_hw=None):
+        """rule_hw: (H, W) of the plane the REFERENCE evaluates this layer on, when x holds only some of its positions
+        (a shape-dependent summation rule follows the reference's call, not this launch's)"""
         _dev(x)
         N, H, W, Cin = x.shape
         if Cin != self.Cin:
@@ -142,7 +144,7 @@ class Conv2d:
         for r in (res1, res2):
             assert r is None or tuple(r.shape) == shp
         L = _lib.hip()
-        rule = self.rule(N, H, W) if callable(self.rule) else self.rule
+        rule = self.rule(N, *(rule_hw or (H, W))) if callable(self.rule) else self.rule
         if self.few:
             _lib.check(L.pmctf_conv2d_fewcout_f32(_p(x), _p(self.w), _p(self.b), _p(res1), _p(res2), _p(y), N, H, W, Cin,
                                                   self.Cout, self.KH, int(act), float(slope), rule, _stream()),

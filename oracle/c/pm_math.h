@@ -12,14 +12,15 @@
  *   torch.tanh     pMCTF/layers/lifting_1d.py:39,42 ; pMCTF/layers/long_context.py:26,32
  *   torch.sigmoid  pMCTF/layers/long_context.py:24,25,31
  *   torch.log      pMCTF/entropy_models/entropy_models.py:271
- * exp / sigmoid / log agree with libm to <= 2 ulp (checked in tests/test_oracle_math.py); tanh is bit for bit the
- * reference's (MKL's schedule, see pm_tanhf).
+ * tanh, log and sigmoid are bit for bit the reference's (MKL VML's schedules for tanh and log, SLEEF's expf for
+ * sigmoid: see pm_tanhf, pm_logf, pm_sleef_f32.h); exp agrees with libm to <= 2 ulp (tests/test_oracle_math.py).
  */
 #ifndef PM_MATH_H
 #define PM_MATH_H
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include "pm_sleef_f32.h"
 
 static inline float pm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t pm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -90,8 +91,10 @@ static inline float pm_tanhf(float x) {
     return pm_u2f(pm_f2u(r) | (ux & PM_TANH_SIGN));
 }
 
+/* torch.sigmoid of a float CPU tensor = 1 / (1 + Sleef_expf16_u10(0 - x)): the routine's instruction sequence is
+ * restated in pm_sleef_f32.h (tools/sleef_transcribe.py, verified against torch.sigmoid). */
 static inline float pm_sigmoidf(float x) {
-    return 1.0f / (1.0f + pm_expf(-x));
+    return pm_aten_sigmoidf(x);
 }
 
 /* natural log: the schedule of Intel MKL's vmsLn (high accuracy, AVX-512 kernel), which IS torch.log for a float32 CPU

@@ -19,7 +19,8 @@ fixtures under tests/golden were generated on):
 
 It was fitted and checked against F.conv2d bit for bit on ~300 (Cin, Cout, H, W) combinations by
 tools/aten_conv_rules.py --fit (profiles/round4_aten_conv_rules.md); planes on which ATen does not use oneDNN at all for
-a 1x1 layer (one image of at most 20 480 input elements) are outside it and keep the chain.
+a 1x1 layer (one image of at most 20 480 input elements: sgemm, one chain from zero, bias last) are handled in
+`conv1x1_sum_rule` for layers of up to 16 input channels and otherwise keep the chain.
 """
 
 
@@ -68,7 +69,10 @@ def onednn_1x1_reduce_block(cin, cout, h, w):
 def conv1x1_sum_rule(cin, cout, n, h, w):
     """sum_rule argument (include/pmctf_hip.h) of a 1x1, stride-1 layer of the signal path whose reference tensor is
     (n, cin, h, w): PMCTF_SUM_CHAIN, or the block size B of "reduce-B"."""
-    if n == 1 and cin * h * w <= 20480:         # ATen does not take the oneDNN path here (Convolution.cpp use_mkldnn)
-        return 0
+    if n == 1 and cin * h * w <= 20480:
+        # ATen does not take the oneDNN path here (Convolution.cpp use_mkldnn) but a plain sgemm: ONE chain from zero, the
+        # bias added last.  For up to 16 input channels that is rule "blocks" (1); wider layers on such small planes
+        # (frames of a few hundred pixels a side) have no rule here and keep the chain from the bias.
+        return 1 if cin <= 16 else 0
     b = onednn_1x1_reduce_block(cin, cout, h, w)
     return b if b < cin and b % 16 == 0 else 0

@@ -57,8 +57,9 @@ def get_curr_q(q_scale, q_index):
 
 
 class Oracle:
-    def __init__(self, state_dict, num_me_stages=1, backend="cdef", decomp_levels=4):
+    def __init__(self, state_dict, num_me_stages=1, backend="cdef", decomp_levels=4, aten_all=False):
         self.K = CdefK() if backend == "cdef" else TorchK()
+        self.aten_all = aten_all   # PM-F32 back-end: ATen's summation order in every layer (the product's "f32-aten")
         self.num_me_stages = num_me_stages
         self.L = decomp_levels
         sd = {k: v.detach().clone().float() for k, v in state_dict.items()}
@@ -80,20 +81,22 @@ class Oracle:
 
     SIGNAL_PATH = ("optic_flow.", "mv_", "temporal_filtering.")
 
-    @classmethod
-    def sum_rule(cls, p, x, w, groups=1, stride=1):
+    def sum_rule(self, p, x, w, groups=1, stride=1):
         """Summation rule of the PM-F32 back-end for the convolution with parameter key p (oracle/c/pm_ops.c: 0 = one chain
-        from the bias, 1 = per-16-channel-block sums from zero added in turn, bias after the first block).  KH*KW > 1
-        layers of the signal path (motion estimation, motion codec, temporal and spatial lifting) follow rule 1, which is
-        what ATen's CPU path computes for them (measured: tools/aten_conv_rules.py); everything else rule 0.  One
+        from the bias, 1 = per-16-channel-block sums from zero added in turn, bias after the first block, B >= 16 = a 1x1
+        layer's reduction in blocks of B channels).  KH*KW > 1 layers of the signal path (motion estimation, motion codec,
+        temporal and spatial lifting) and of the post-processing CNN follow rule 1, which is what ATen's CPU path computes
+        for them (measured: tools/aten_conv_rules.py); 1x1 layers the chain unless ATen blocks the reduction
+        (aten_rules); the entropy-parameter networks rule 0 — or, with aten_all, ATen's order like the signal path.  One
         shape-dependent exception, also ATen's: a lifting step's 3x1 filter whose (reflect-padded) input is ONE plane of
         at most 20 480 elements does not go through oneDNN (Convolution.cpp `use_mkldnn`) but through im2col + gemv,
         which starts from the bias — rule 0."""
-        if groups != 1 or not (p.startswith(cls.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
+        if groups != 1:
+            return 0
+        if not (self.aten_all or p.startswith(self.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return 0
         if w.size(2) * w.size(3) == 1:
-            # 1x1 layers: one chain from the bias, unless ATen's jit_1x1 kernel blocks the reduction (aten_rules: B channels)
-            if w.size(1) >= 112 and stride == 1:
+            if stride == 1 and (w.size(1) >= 112 or self.aten_all):
                 return aten_rules.conv1x1_sum_rule(w.size(1), w.size(0), x.size(0), x.size(2), x.size(3))
             return 0
         if w.size(0) == 1 and w.size(1) == 1 and w.size(3) == 1 and x.size(0) == 1 and x.numel() <= 20480:

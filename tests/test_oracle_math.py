@@ -78,6 +78,23 @@ def test_tanh_and_log_are_the_reference_s_bit_for_bit():
         assert np.array_equal(clib.log(s).view(np.uint32), torch.log(torch.from_numpy(s)).numpy().view(np.uint32))
 
 
+def test_sigmoid_is_the_reference_s_bit_for_bit():
+    """pm_aten_sigmoidf (pm_sleef_f32.h: 1 / (1 + Sleef_expf16_u10(0 - x)), the routine torch.sigmoid runs on a float CPU
+    tensor) against a fixture of torch's outputs (tools/make_sigmoid_fixture.py), and live where this machine's torch
+    agrees with the fixture.  The oracle's and the product's copy of the generated header are one text."""
+    import os
+    from pmctf_oracle import clib
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "reference_torch_sigmoid.npz"))
+    assert np.array_equal(clib.sigmoid(g["sigmoid_x"]).view(np.uint32), g["sigmoid_y"].view(np.uint32))
+    if np.array_equal(torch.sigmoid(torch.from_numpy(g["sigmoid_x"])).numpy().view(np.uint32), g["sigmoid_y"].view(np.uint32)):
+        x = (np.random.default_rng(12).standard_normal(1 << 21) * 6).astype(np.float32)
+        assert np.array_equal(clib.sigmoid(x).view(np.uint32), torch.sigmoid(torch.from_numpy(x)).numpy().view(np.uint32))
+    root = os.path.dirname(here)
+    assert open(os.path.join(root, "oracle", "c", "pm_sleef_f32.h")).read() == \
+        open(os.path.join(root, "learned-pmctf_amd", "csrc", "pm_sleef_f32.h")).read()
+
+
 def test_signal_path_convolutions_are_aten_s_bit_for_bit():
     """The summation rules of the signal path (oracle/c/pm_ops.c rule 1 for KH*KW > 1, the chain or oneDNN's blocked
     reduction for 1x1: pmctf_oracle.aten_rules) reproduce F.conv2d bit for bit on the layer shapes of the path — checked

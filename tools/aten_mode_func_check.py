@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Function-level HIP ("f32-aten") vs oracle (PM-F32, aten_all) comparison of the entropy-parameter networks. GPU tool."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("learned-pmctf_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+os.environ["PMCTF_PRECISION"] = sys.argv[1] if len(sys.argv) > 1 else "f32-aten"
+import numpy as np, torch
+from helpers import product_model
+from pmctf_oracle.model import Oracle
+
+net, sd = product_model(1)
+eng = net.engine()
+orc = Oracle(sd, 1, "cdef", aten_all=eng.aten_all)
+g = torch.Generator().manual_seed(1)
+
+
+def cmp(name, a, b):
+    a = a.detach().cpu()
+    if a.dim() == 4 and a.shape != b.shape:
+        a = a.permute(0, 3, 1, 2)
+    a, b = a.contiguous().numpy(), b.contiguous().numpy()
+    d = int((a.view(np.int32) != b.view(np.int32)).sum())
+    print(f"{'DIFF' if d else 'ok  '} {name:50s} {tuple(b.shape)} differing {d}", flush=True)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+with torch.no_grad():
+    for coder in ("hp_coder", "lp_coder"):
+        for N in (1, 2):
+            h, w = 24, 40
+            ll = torch.randint(-40, 40, (N, 1, h, w), generator=g).float()
+            cmp(f"{coder} N={N} context_fusion_ll", eng.context_fusion_ll(coder, ll.cuda()), orc.context_fusion_ll(coder, ll))
+            # conv-LSTM context over the subbands of two levels
+            st = eng.ctx_init(N, h, w)
+            orc.ctx_init([N, 1, h, w])
+            hh, ww = h, w
+            for lvl in (3, 2):
+                for sb in ("ll", "lh", "hl", "hh") if lvl == 3 else ("lh", "hl", "hh"):
+                    s = torch.randint(-30, 30, (N, 1, hh, ww), generator=g).float()
+                    c_e = eng.ctx_forward_one_subband(coder, st, s.cuda(), sb, lvl)
+                    c_o = orc.ctx_forward_one_subband(coder, s, sb, lvl)
+                    cmp(f"{coder} N={N} context after {lvl}.{sb}", c_e, c_o)
+                hh, ww = hh * 2, ww * 2
+            # pieces of the four-step fusion
+            for lvl, prev in ((3, False), (2, True)):
+                p = f"{coder}.context_fusion.{lvl}.lh"
+                ctx = torch.randn(N, 1, h, w, generator=g)
+                c = ctx
+                if prev:
+                    pv = torch.randint(-20, 20, (N, 1, h // 2, w // 2), generator=g).float()
+                    from pMCTF.hip import ops
+                    up = ops.nearest_up2(pv.cuda().view(N, h // 2, w // 2, 1))
+                    e_prev = eng.conv(p + ".lower_level_subband.1", 1, 1)(up)
+                    o_prev = orc.conv(p + ".lower_level_subband.1", torch.nn.functional.interpolate(pv, scale_factor=2, mode="nearest"), padding=1)
+                    cmp(f"{p} lower_level_subband", e_prev, o_prev)
+                    c = torch.cat((ctx, o_prev), dim=1)
+                e = eng.conv(p + ".conv1_context", 1, 1)(nhwc(c))
+                o = orc.conv(p + ".conv1_context", c, padding=1)
+                cmp(f"{p} conv1_context", e, o)
+                e2 = eng.context_residual(p + ".y_hierarchical_prior_enc.0", nhwc(o))
+                o2 = orc.context_residual(p + ".y_hierarchical_prior_enc.0", o)
+                cmp(f"{p} prior_enc.0", e2, o2)
+                e3 = eng.depth_conv_block(p + ".y_hierarchical_prior_out", nhwc(o2))
+                o3 = orc.depth_conv_block(p + ".y_hierarchical_prior_out", o2)
+                cmp(f"{p} prior_out (depth conv block)", e3, o3)
+                sf = torch.randint(-20, 20, (N, 1, h, w), generator=g).float()
+                e4 = eng.conv(f"{p}.y_spatial_prior_1.0", 1, 1)(nhwc(sf))
+                o4 = orc.conv(f"{p}.y_spatial_prior_1.0", sf, padding=1)
+                cmp(f"{p} spatial_prior_1.0", e4, o4)
+                e5 = eng.context_residual(f"{p}.y_spatial_prior_1.1", nhwc(o4), res2=nhwc(o2))
+                o5 = orc.context_residual(f"{p}.y_spatial_prior_1.1", o4) + o2
+                cmp(f"{p} spatial_prior_1.1 + context", e5, o5)
+                q = f"{p}.y_spatial_prior_1_out.1"
+                from pMCTF.hip import ops
+                from pMCTF.hip.engine import ACT_LEAKY, EW_COPY, ew, as_nchw
+                t = nhwc(o5)
+                oo = eng.conv(q + ".conv1", 1, 1)(t, act=ACT_LEAKY, slope=0.2)
+                tq = ops.empty_nhwc(N, h // 2, w // 2, t.shape[3], eng.dev)
+                ew(EW_COPY, as_nchw(t)[:, :, 0::2, 1::2], out=as_nchw(tq))
+                tq = ops.conv_at_class(eng.conv(q + ".conv2", 1, 1), oo, 1, res1=tq)
+                e6 = eng.conv(f"{p}.y_spatial_prior_1_out.2")(tq)
+                o6 = orc.conv(f"{p}.y_spatial_prior_1_out.2", orc.context_residual(q, o5))[:, :, 0::2, 1::2]
+                cmp(f"{p} spatial_prior_1_out.1/.2 at class 1", e6, o6)

@@ -9,7 +9,8 @@ decisions depend on those bits.  The generated header (plain C, also valid HIP d
 and the GPU kernels reproduce ATen's values bit for bit.  Build-container tool: it reads the machine code and the
 constants of the torch installation it runs under and verifies the result against torch itself.
 
-  python tools/sleef_transcribe.py OUT.h        # writes the header, then checks it against torch on ~10^8 inputs
+  python tools/sleef_transcribe.py [OUT.h]      # writes the header (default: the oracle's and the product's copy), then
+                                                # checks it against torch on ~10^8 inputs
 """
 import ctypes
 import os
@@ -178,6 +179,9 @@ HEADER = '''/* GENERATED by tools/sleef_transcribe.py — do not edit.
  * Sleef_expf16_u10 (torch.exp, torch.sigmoid = 1 / (1 + exp(-x))), Sleef_logf16_u10 (torch.log), Sleef_tanhf16_u10
  * (torch.tanh).  Every operation is a single IEEE binary32 operation (fmaf where the machine code fuses), so the values
  * equal ATen's bit for bit; verified by the generator against torch on ~10^8 inputs per function including every special.
+ * (ATen evaluates only whole 16-float vectors this way: the last numel %% 32 elements of each thread's slice of a tensor go
+ * through the scalar lambda, i.e. glibc's expf, which differs from SLEEF in the last bit on a few inputs per million.  The
+ * gate tensors of the path have 32 channels per plane, so their slices hold whole vectors only.)
  * Valid as C (oracle) and as HIP device code (product): define PM_SLEEF_FN before including.
  */
 #ifndef PM_SLEEF_F32_H
@@ -186,7 +190,7 @@ HEADER = '''/* GENERATED by tools/sleef_transcribe.py — do not edit.
 #ifndef PM_SLEEF_FN
 #define PM_SLEEF_FN static inline
 #endif
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIPCC__)
 #define PM_U(f) __float_as_uint(f)
 #define PM_F(u) __uint_as_float(u)
 #define PM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -323,7 +327,10 @@ def verify(header):
 
 
 if __name__ == "__main__":
-    out = sys.argv[1]
-    generate(out)
-    print("wrote", out)
-    sys.exit(0 if verify(out) else 1)
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = sys.argv[1:] or [os.path.join(ROOT, "oracle", "c", "pm_sleef_f32.h"),
+                            os.path.join(ROOT, "learned-pmctf_amd", "csrc", "pm_sleef_f32.h")]
+    for out in outs:                       # the oracle's copy and the product's copy: one text (tests/test_oracle_math.py)
+        generate(out)
+        print("wrote", out)
+    sys.exit(0 if verify(outs[0]) else 1)
