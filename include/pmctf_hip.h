@@ -306,6 +306,14 @@ int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *stream_words, 
                            int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets, int cdf_cols,
                            float log_scale_min, float log_scale_step, float *ll_out, float *scratch_zeroed, int N, int H,
                            int W, uint64_t *state_out, void *stream);
+/* The same decode under the summation rules the encoder's one-shot LL network ran with (PMCTF_SUM_*): sum_rule_3x3 for
+ * the masked 3x3 layers (CHAIN or BLOCKS), sum_rule_head for convs.0 / convs.1 and sum_rule_head_out for convs.2
+ * (CHAIN, or the block size B of "reduce-B", a multiple of 16).  pmctf_ll_ar_decode_f32 = all three CHAIN. */
+int pmctf_ll_ar_decode_rules_f32(const float *w_packed, const uint32_t *stream_words, int64_t n_words, uint64_t x0,
+                                 int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets,
+                                 int cdf_cols, float log_scale_min, float log_scale_step, float *ll_out,
+                                 float *scratch_zeroed, int N, int H, int W, uint64_t *state_out, int sum_rule_3x3,
+                                 int sum_rule_head, int sum_rule_head_out, void *stream);
 /* ContextFusionFourStep.decompress (context_fusion_4step.py:196-249): CDF rows handed to decode_stream for step k
  * (0 off the mask), then x_hat = (q + mean) on the mask.  params as in pmctf_fourstep_quant_f32. */
 int pmctf_fourstep_indexes_f32(const float *params, int16_t *idx, int N, int H, int W, int k, int params_sub,

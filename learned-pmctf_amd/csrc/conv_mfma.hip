@@ -511,7 +511,7 @@ _Pragma("unroll")
 // compiler keeps one set in AGPRs); the rule-0 instantiation measured the same 137 TFLOP/s at one workgroup per CU
 // (docs/history.md section 9), i.e. the kernel is MFMA-bound, not occupancy-bound.
 template <int MT, int NBUF, bool BSUM = false>
-__global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)) void conv3x3s1_wave_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (BSUM && MT >= 7) ? 1 : (NBUF == 1 ? 3 : 2)) void conv3x3s1_wave_kernel(ConvArgs a) {
     constexpr int NT = 4, LH = 6, LW = 18, MAXP = 7;
     constexpr int BUFSZ = LH * LW * CP;
     constexpr int E = LH * LW * 4;
@@ -529,17 +529,31 @@ __global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)
     const int iy0 = oy0 - a.pad_h, ix0 = ox0 - a.pad_w;
     float *wlds = lds + wave * NBUF * BUFSZ;
 
+    // BSUM: `tot` starts as the bias and takes every chunk's sum when it is complete (S_0 + bias = bias + S_0 exactly).
+    // With 7 cout tiles the two sets are 224 registers: `tot` is pinned to the accumulation registers (AGPRs) by giving
+    // every access of it an "a" operand — left to itself the allocator keeps both sets in VGPRs and spills inside the loop.
+    constexpr bool TOT_AGPR = BSUM && MT >= 7;
     f32x4 acc[MT][NT];
-    f32x4 tot[BSUM ? MT : 1][BSUM ? NT : 1];
+    f32x4 tot[BSUM && !TOT_AGPR ? MT : 1][BSUM && !TOT_AGPR ? NT : 1];
+    float tota[TOT_AGPR ? MT : 1][TOT_AGPR ? NT : 1][4];
     {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = BSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(bp + mt * 16);
+            const f32x4 b = *(const f32x4 *)(bp + mt * 16);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b;
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (TOT_AGPR) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm("v_accvgpr_write_b32 %0, %1" : "=a"(tota[mt][nt][e]) : "v"(b[e]));
+                } else if constexpr (BSUM) {
+                    tot[mt][nt] = b;
+                }
+                acc[mt][nt] = b;
+            }
         }
     }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // staging: lane owns float4 slots e = lane + 64*j of this wave's patch (pixel e>>2, channel quad e&3); bounds and
     // byte offsets inside image n are fixed for the tile, slots outside the image stay zero for ever
     bool ok[MAXP];
@@ -611,7 +625,8 @@ __global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0[nt],
+                                                                        (BSUM && t == 0) ? zero4 : acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b0[nt] = cur[nt * LW * CP + toff + 8];
             __builtin_amdgcn_sched_barrier(0);
@@ -642,17 +657,23 @@ __global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)
         // nine taps: the next chunk's first fragments arrived in set 1
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
-        if constexpr (BSUM) {       // the chunk's sums are complete: (S_0 + bias), + S_1, ...
-            const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
+        if constexpr (BSUM) {       // the chunk's sums are complete: (bias + S_0), + S_1, ...; the next chunk starts from zero
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 b = *(const f32x4 *)(bp + mt * 16);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    tot[mt][nt] = cb == 0 ? acc[mt][nt] + b : tot[mt][nt] + acc[mt][nt];
-                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (TOT_AGPR) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t;
+                            asm("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(tota[mt][nt][e]));
+                            t = t + acc[mt][nt][e];
+                            asm("v_accvgpr_write_b32 %0, %1" : "=a"(tota[mt][nt][e]) : "v"(t));
+                        }
+                    } else {
+                        tot[mt][nt] = tot[mt][nt] + acc[mt][nt];
+                    }
                 }
-            }
         }
         // the other buffer was last read in chunk cb-1 by this same wave (NBUF = 1: this buffer, all of whose reads have
         // been issued by now): in-order LDS makes the overwrite safe
@@ -662,7 +683,14 @@ __global__ __launch_bounds__(256, BSUM ? (MT >= 7 ? 1 : 2) : (NBUF == 1 ? 3 : 2)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = tot[mt][nt];
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (TOT_AGPR) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm("v_accvgpr_read_b32 %0, %1" : "=v"(acc[mt][nt][e]) : "a"(tota[mt][nt][e]));
+                } else {
+                    acc[mt][nt] = tot[mt][nt];
+                }
+            }
     }
 
     PM_EPILOGUE_NOTRANS(a,
@@ -687,7 +715,7 @@ _Pragma("unroll")
 // = one register + immediates, staging offsets and bounds computed once — with the workgroup-shared, double-buffered
 // 6x18 patch and one barrier per 16-channel chunk of conv_mfma_pipe_kernel<MT,1,1,.>.  A wave owns one tile row.
 // S = 2: the stride-2 form of the quarter-resolution context convolutions (9x33 patch).
-template <int MT, int S = 1>
+template <int MT, int S = 1, bool BSUM = false>
 __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
     constexpr int LH = 3 * S + 3, LW = 15 * S + 3;
     constexpr int BUFSZ = LH * LW * CP;
@@ -705,11 +733,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
     const int iy0 = oy0 * S - a.pad_h, ix0 = ox0 * S - a.pad_w;
 
     f32x4 acc[MT];
+    f32x4 tot[BSUM ? MT : 1];          // rule "blocks": starts as the bias, takes every chunk's sum when it is complete
     {
         const float *bp = a.bp + (size_t)mtile0 * 16 + 4 * (lane >> 4);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = *(const f32x4 *)(bp + mt * 16);
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = *(const f32x4 *)(bp + mt * 16);
+            if constexpr (BSUM) tot[mt] = acc[mt];
+        }
     }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     bool ok[MAXP];
     unsigned goff[MAXP];
     f32x4 pre[MAXP];
@@ -773,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t & 1][mt][0], b0, (BSUM && t == 0) ? zero4 : acc[mt], 0, 0, 0);
             b0 = cur[toff + 8];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -792,8 +825,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) wf[0][mt] = wf[1][mt];
+        if constexpr (BSUM) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) tot[mt] = tot[mt] + acc[mt];
+        }
         if (more) stash((cb + 1) & 1);
         __syncthreads();
+    }
+    if constexpr (BSUM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = tot[mt];
     }
 
     {
@@ -1591,14 +1632,25 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
                 return pm_launch_status();
             }
         }
-        if constexpr (NT == 4 && TW16 == 2 && (MT == 4 || MT == 7)) {
-            if (sc.bchunks == 1 && !sc.bias_first && a.act <= pm::ACT_LEAKY && a.KH == 3 && a.KW == 3 && a.S == 1 &&
-                wave_eligible(a) && knob("K33") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32)) {
+        const bool plain_blocks = sc.bchunks == 1 && !sc.bias_first && a.act <= pm::ACT_LEAKY && a.KH == 3 && a.KW == 3 &&
+                                  knob("K33") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32);
+        if constexpr (NT == 4 && TW16 == 2 && (MT == 1 || MT == 2 || MT == 4 || MT == 7)) {
+            if (plain_blocks && a.S == 1 && wave_eligible(a)) {
                 const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
-                const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+                constexpr int NB = MT <= 2 ? 1 : 2;       // narrow layers: single patch buffer, three workgroups per CU
+                const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * NB * WAVES;
                 static std::once_flag once_kb;
-                allow_big_lds(conv3x3s1_wave_kernel<MT, 2, true>, once_kb);
-                CONV_LAUNCH((conv3x3s1_wave_kernel<MT, 2, true>), grid, dim3(256), wsmem, st, b);
+                allow_big_lds(conv3x3s1_wave_kernel<MT, NB, true>, once_kb);
+                CONV_LAUNCH((conv3x3s1_wave_kernel<MT, NB, true>), grid, dim3(256), wsmem, st, b);
+                return pm_launch_status();
+            }
+        }
+        if constexpr (NT == 1 && TW16 == 1 && (MT == 1 || MT == 7 || MT == 8)) {
+            // 4x16 tiles: the pipelined 3x3 kernels (mid-size planes, remainder rows, the stride-2 quarter-resolution form)
+            const int slots = (LH * LW * 4 + 255) / 256;
+            if (plain_blocks && (a.S == 1 || a.S == 2) && (a.Cin % CB) == 0 && 2 * smem <= 80 * 1024 && slots <= 9) {
+                if (a.S == 1) CONV_LAUNCH((conv3x3s1_pipe_kernel<MT, 1, true>), grid, dim3(256), 2 * smem, st, b);
+                else CONV_LAUNCH((conv3x3s1_pipe_kernel<MT, 2, true>), grid, dim3(256), 2 * smem, st, b);
                 return pm_launch_status();
             }
         }

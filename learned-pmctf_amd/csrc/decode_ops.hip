@@ -49,7 +49,20 @@ struct LLArgs {
     float *bufs;                  // 5 activation buffers [N][(H+1)][(W+2)][NF], zero-initialised by the caller
     int N, H, W;
     unsigned long long *state_out;  // [0] = x, [1] = word position, [2] = error flag
+    // summation rules (include/pmctf_hip.h PMCTF_SUM_*), the same the encoder's one-shot network runs under:
+    int blocks;                   // masked 3x3 layers: 0 = one chain from the bias, 1 = per-16-channel-block sums ("blocks")
+    unsigned head_mask[3];        // 1x1 head layers convs.0/1/2: bit cb set = a reduction block ("reduce-B") ends before
+    int head_b[3];                // 16-channel chunk cb; head_b = B (0: one chain)
 };
+
+// reduce-B over 128 input channels: which 16-channel chunks start a new block
+inline unsigned reduce_mask(int B) {
+    unsigned m = 0;
+    if (B >= 16 && B < NF)
+        for (int cb = 1; cb < NF / 16; ++cb)
+            if ((cb * 16) % B == 0) m |= 1u << cb;
+    return m;
+}
 
 // offsets (in floats) inside the packed weight blob
 constexpr long W_L0 = 0;                                  // [4 taps][NF]      maskedConv1 (type A, Cin = 1)
@@ -76,8 +89,10 @@ constexpr long W_TOTAL = S_P2 + 2 * NF + 2;
 __device__ __forceinline__ float leaky02(float v) { return v > 0.0f ? v : v * 0.2f; }
 
 // type-B masked 3x3, 128 -> 128, at one position: act[t][ch] in LDS (t = causal tap), one output channel per thread
-__device__ __forceinline__ float masked_b(const float *__restrict__ wl, const float *act, int co) {
-    float acc = wl[(long)8 * TB * 16 * NF + co];           // bias
+// blocks: every 16-channel chunk's sum starts from zero; (S_0 + bias) + S_1 + ... (rule "blocks")
+__device__ __forceinline__ float masked_b(const float *__restrict__ wl, const float *act, int co, int blocks) {
+    const float bias = wl[(long)8 * TB * 16 * NF + co];
+    float acc = blocks ? 0.0f : bias, tot = 0.0f;
     const float *wp = wl + co;
 #pragma unroll 1
     for (int cb = 0; cb < 8; ++cb) {
@@ -87,18 +102,30 @@ __device__ __forceinline__ float masked_b(const float *__restrict__ wl, const fl
 #pragma unroll
             for (int ci = 0; ci < 16; ++ci) acc = __builtin_fmaf(a[ci], wp[(long)((cb * TB + t) * 16 + ci) * NF], acc);
         }
+        if (blocks) {
+            tot = cb == 0 ? acc + bias : tot + acc;
+            acc = 0.0f;
+        }
     }
-    return acc;
+    return blocks ? tot : acc;
 }
 
-__device__ __forceinline__ float dense128(const float *__restrict__ wl, const float *act, int co, int nout) {
-    float acc = wl[(long)NF * nout + co];
+// mask / B: "reduce-B" of a 1x1 layer (the first block's chain starts at the bias, later blocks at zero, block results
+// added in turn); mask = 0: one chain
+__device__ __forceinline__ float dense128(const float *__restrict__ wl, const float *act, int co, int nout, unsigned mask,
+                                          int B) {
+    float acc = wl[(long)NF * nout + co], tot = 0.0f;
     const float *wp = wl + co;
 #pragma unroll 1
-    for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < 8; ++cb) {
+        if ((mask >> cb) & 1u) {
+            tot = cb * 16 == B ? acc : tot + acc;
+            acc = 0.0f;
+        }
 #pragma unroll
         for (int ci = 0; ci < 16; ++ci) acc = __builtin_fmaf(act[cb * 16 + ci], wp[(long)(cb * 16 + ci) * nout], acc);
-    return acc;
+    }
+    return mask ? tot + acc : acc;
 }
 
 constexpr int LL_MAX_PLANES = 4;          // one 128-thread group per plane of the stream (Y: 1, UV: 2, RGB: 3)
@@ -137,11 +164,12 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
                 }
                 if (wq > 0) v10 = cur[(long)h * a.W + wq - 1];
             }
-            float t = b0;
+            float t = a.blocks ? 0.0f : b0;           // one input channel = one block: bias last under "blocks"
             t = __builtin_fmaf(v00, w00, t);
             t = __builtin_fmaf(v01, w01, t);
             t = __builtin_fmaf(v02, w02, t);
             t = __builtin_fmaf(v10, w10, t);
+            if (a.blocks) t = t + b0;
             const float conv1 = t;
             // position (h, wq) lives at buffer row h+1, column wq+1
             const long cpos = ((long)(h + 1) * PW + (wq + 1)) * NF + co;
@@ -161,7 +189,7 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
                 }
                 __syncthreads();
                 float o = 0.f;
-                if (live) o = masked_b(w + W_MB + layer * SZ_MB, act[plane], co);
+                if (live) o = masked_b(w + W_MB + layer * SZ_MB, act[plane], co, a.blocks);
                 __syncthreads();
                 if (layer == 0 || layer == 2) {            // conv1 of a residual block: leaky, keep block input in xres
                     vec[plane][co] = xin;                   // (own slot: no race)
@@ -177,16 +205,16 @@ __global__ __launch_bounds__(128 * LL_MAX_PLANES) void ll_ar_decode_kernel(LLArg
             if (live) act[plane][co] = xin;
             __syncthreads();
             float p0 = 0.f;
-            if (live) p0 = leaky02(dense128(w + W_P0, act[plane], co, NF));
+            if (live) p0 = leaky02(dense128(w + W_P0, act[plane], co, NF, a.head_mask[0], a.head_b[0]));
             __syncthreads();
             if (live) act[plane][co] = p0;
             __syncthreads();
             float p1 = 0.f;
-            if (live) p1 = leaky02(dense128(w + W_P1, act[plane], co, NF));
+            if (live) p1 = leaky02(dense128(w + W_P1, act[plane], co, NF, a.head_mask[1], a.head_b[1]));
             __syncthreads();
             if (live) act[plane][co] = p1;
             __syncthreads();
-            if (live && co < 2) prm[plane][co] = dense128(w + W_P2, act[plane], co, 2);
+            if (live && co < 2) prm[plane][co] = dense128(w + W_P2, act[plane], co, 2, a.head_mask[2], a.head_b[2]);
             __syncthreads();
             // ---- entropy decode (wave 0, uniform): plane 0 then plane 1 (pWave.py:566-575 with B planes)
             if (tid < 64) {
@@ -298,6 +326,7 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
     for (int i = tid; i < 2 * NF + 2; i += NF) l_p2[i] = a.w[S_P2 + i];
     for (int i = tid; i < 7 * NF; i += NF) l_bias[i] = a.w[S_BIAS + i];
     const float *w = a.w;
+    const bool blocks = a.blocks != 0;
     const float w00 = w[W_L0 + 0 * NF + tid], w01 = w[W_L0 + 1 * NF + tid], w02 = w[W_L0 + 2 * NF + tid],
                 w10 = w[W_L0 + 3 * NF + tid], b0 = w[B_L0 + tid];
     const f32x4 *ws = (const f32x4 *)(w + S_W) + tid;     // group g of this channel: ws[g * NF]
@@ -346,11 +375,12 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const float *rp = row_prev + p * 2 * (W + 2) + wq, *rc = row_cur + p * 2 * (W + 2) + wq;
-                float t = b0;                             // padded rows: column wq-1 is at index wq
+                float t = blocks ? 0.0f : b0;             // padded rows: column wq-1 is at index wq
                 t = __builtin_fmaf(rp[0], w00, t);
                 t = __builtin_fmaf(rp[1], w01, t);
                 t = __builtin_fmaf(rp[2], w02, t);
                 t = __builtin_fmaf(rc[0], w10, t);
+                if (blocks) t = t + b0;
                 conv1[p] = t;
                 xin[p] = t;
                 xres[p] = 0.0f;
@@ -375,9 +405,10 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
                     lf[0] = xin[p];
                 }
                 __syncthreads();
-                float acc[NP];
+                float acc[NP], tot[NP];
+                const float lbias = l_bias[layer * NF + tid];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p] = l_bias[layer * NF + tid];
+                for (int p = 0; p < NP; ++p) { acc[p] = blocks ? 0.0f : lbias; tot[p] = 0.0f; }
                 // activations of a block are read from LDS one block ahead of their use (the chain must never wait for them)
                 f32x4 ab[2][NP][BLK];
                 auto read_act = [&](int blk, int buf) {
@@ -396,6 +427,14 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
                     if (blk + 1 < BLOCKS_B) read_act(blk + 1, (blk + 1) & 1);
 #pragma unroll
                     for (int g = 0; g < BLK; ++g) {
+                        const int k0 = (blk * BLK + g) * 4;               // chain index: a 16-channel chunk is 80 terms
+                        if (k0 > 0 && k0 % (TB * 16) == 0 && blocks) {    // rule "blocks": the chunk's sum is complete
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {
+                                tot[p] = k0 == TB * 16 ? acc[p] + lbias : tot[p] + acc[p];
+                                acc[p] = 0.0f;
+                            }
+                        }
                         const f32x4 wv = ring[blk % RING][g];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -410,7 +449,7 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
                 }
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const float o = acc[p];
+                    const float o = blocks ? tot[p] + acc[p] : acc[p];
                     if (layer == 0 || layer == 2) { xres[p] = xin[p]; xin[p] = leaky02(o); }
                     else if (layer == 1) xin[p] = o + xres[p];
                     else if (layer == 3) xin[p] = (o + xres[p]) + conv1[p];
@@ -424,9 +463,11 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) A[p * TB * NF + tid] = xin[p];
                 __syncthreads();
-                float acc[NP];
+                float acc[NP], tot[NP];
+                const unsigned hmask = a.head_mask[d];
+                const int hb = a.head_b[d];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p] = l_bias[(5 + d) * NF + tid];
+                for (int p = 0; p < NP; ++p) { acc[p] = l_bias[(5 + d) * NF + tid]; tot[p] = 0.0f; }
 #pragma unroll
                 for (int blk = 0; blk < BLOCKS_D; ++blk) {
                     request((blk + RING - 1) % RING);
@@ -434,6 +475,13 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
 #pragma unroll
                         for (int g = 0; g < BLK; ++g) {
                             const int k = (blk * BLK + g) * 4;
+                            if (k % 16 == 0 && ((hmask >> (k / 16)) & 1u)) {      // "reduce-B": a block of the reduction ends
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) {
+                                    tot[p] = k == hb ? acc[p] : tot[p] + acc[p];
+                                    acc[p] = 0.0f;
+                                }
+                            }
                             const f32x4 wv = ring[blk % RING][g];
 #pragma unroll
                             for (int p = 0; p < NP; ++p) {
@@ -449,7 +497,7 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < NP; ++p) xin[p] = leaky02(acc[p]);
+                for (int p = 0; p < NP; ++p) xin[p] = leaky02(hmask ? tot[p] + acc[p] : acc[p]);
             }
             {
                 float *A = l_act + (7 & 1) * NP * TB * NF;
@@ -458,11 +506,19 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
                 __syncthreads();
                 if (tid < 2 * NP) {                       // (plane, output) pairs: scale and mean of every plane
                     const int p = tid >> 1, o = tid & 1;
-                    float acc = l_p2[2 * NF + o];
+                    float acc = l_p2[2 * NF + o], tot = 0.0f;
                     const float *wv = l_p2 + o * NF, *av = A + p * TB * NF;
-#pragma unroll 16
-                    for (int k = 0; k < NF; ++k) acc = __builtin_fmaf(av[k], wv[k], acc);
-                    l_prm[p * 2 + o] = acc;
+                    const unsigned hmask = a.head_mask[2];
+#pragma unroll 1
+                    for (int cb = 0; cb < NF / 16; ++cb) {
+                        if ((hmask >> cb) & 1u) {
+                            tot = cb * 16 == a.head_b[2] ? acc : tot + acc;
+                            acc = 0.0f;
+                        }
+#pragma unroll
+                        for (int k = cb * 16; k < cb * 16 + 16; ++k) acc = __builtin_fmaf(av[k], wv[k], acc);
+                    }
+                    l_prm[p * 2 + o] = hmask ? tot + acc : acc;
                 }
                 __syncthreads();
             }
@@ -692,6 +748,20 @@ extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *str
                                       int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets,
                                       int cdf_cols, float log_scale_min, float log_scale_step, float *ll_out,
                                       float *scratch_zeroed, int N, int H, int W, uint64_t *state_out, void *stream) {
+    return pmctf_ll_ar_decode_rules_f32(w_packed, stream_words, n_words, x0, pos0, cdf, sizes, offsets, cdf_cols, log_scale_min,
+                                        log_scale_step, ll_out, scratch_zeroed, N, H, W, state_out, PMCTF_SUM_CHAIN,
+                                        PMCTF_SUM_CHAIN, PMCTF_SUM_CHAIN, stream);
+}
+
+extern "C" int pmctf_ll_ar_decode_rules_f32(const float *w_packed, const uint32_t *stream_words, int64_t n_words, uint64_t x0,
+                                            int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets,
+                                            int cdf_cols, float log_scale_min, float log_scale_step, float *ll_out,
+                                            float *scratch_zeroed, int N, int H, int W, uint64_t *state_out,
+                                            int sum_rule_3x3, int sum_rule_head, int sum_rule_head_out, void *stream) {
+    if ((sum_rule_3x3 != PMCTF_SUM_CHAIN && sum_rule_3x3 != PMCTF_SUM_BLOCKS) ||
+        (sum_rule_head != PMCTF_SUM_CHAIN && (sum_rule_head < 16 || sum_rule_head % 16)) ||
+        (sum_rule_head_out != PMCTF_SUM_CHAIN && (sum_rule_head_out < 16 || sum_rule_head_out % 16)))
+        return PMCTF_EINVAL;
     if (!w_packed || !stream_words || !cdf || !sizes || !offsets || !ll_out || !scratch_zeroed || !state_out || N < 1 ||
         N > LL_MAX_PLANES || H < 1 || W < 1 || n_words < 0 || cdf_cols < 3)
         return PMCTF_EINVAL;
@@ -701,6 +771,10 @@ extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *str
     a.lmin = log_scale_min; a.lstep = log_scale_step;
     a.ll_out = ll_out; a.bufs = scratch_zeroed; a.N = N; a.H = H; a.W = W;
     a.state_out = (unsigned long long *)state_out;
+    a.blocks = sum_rule_3x3 == PMCTF_SUM_BLOCKS;
+    a.head_b[0] = a.head_b[1] = sum_rule_head;
+    a.head_b[2] = sum_rule_head_out;
+    for (int i = 0; i < 3; ++i) a.head_mask[i] = reduce_mask(a.head_b[i]);
     const size_t smem = ((size_t)256 * cdf_cols + 512) * sizeof(int32_t) +
                         ((size_t)2 * N * TB * NF + 5 * N * NF + 5 * N * 4 * NF + 7 * NF + 2 * NF + 2 + 2 * N +
                          (size_t)N * 2 * (W + 2)) * sizeof(float) + 64;

@@ -1095,9 +1095,16 @@ class HipEngine:
             scratch = torch.zeros(L.pmctf_ll_ar_scratch_floats(N, H, W), dtype=torch.float32, device=self.dev)
             state = torch.zeros(3, dtype=torch.int64, device=self.dev)
             vp = lambda t: C.c_void_p(t.data_ptr())
-            _lib.check(L.pmctf_ll_ar_decode_f32(vp(w), vp(words), words.numel(), C.c_uint64(x), pos, vp(cdf), vp(sizes),
-                                                vp(offsets), cdf.shape[1], float(self.lmin), float(self.lstep), vp(ll),
-                                                vp(scratch), N, H, W, vp(state), C.c_void_p(st.cuda_stream)),
+            # the rules of the encoder's one-shot network (context_fusion_ll), layer for layer
+            p = f"{coder}.context_fusion.{self.L - 1}.ll"
+            rules = []
+            for name in (".maskedConv2", ".convs.0", ".convs.2"):
+                r = self.sum_rule(p + name, self.sd[p + name + ".weight"])
+                rules.append(r(N, H, W) if callable(r) else r)
+            _lib.check(L.pmctf_ll_ar_decode_rules_f32(vp(w), vp(words), words.numel(), C.c_uint64(x), pos, vp(cdf),
+                                                      vp(sizes), vp(offsets), cdf.shape[1], float(self.lmin),
+                                                      float(self.lstep), vp(ll), vp(scratch), N, H, W, vp(state),
+                                                      rules[0], rules[1], rules[2], C.c_void_p(st.cuda_stream)),
                        "ll_ar_decode")
         return {"dec": dec, "ll": ll, "state": state, "stream": st, "keep": (words, scratch)}
 

@@ -62,6 +62,8 @@ _SIGS = {
     "pmctf_ll_ar_pack_weights": (ci, [vp] * 11),
     "pmctf_ll_ar_scratch_floats": (i64, [ci, ci, ci]),
     "pmctf_ll_ar_decode_f32": (ci, [vp, vp, i64, C.c_uint64, i64, vp, vp, vp, ci, cf, cf, vp, vp, ci, ci, ci, vp, vp]),
+    "pmctf_ll_ar_decode_rules_f32": (ci, [vp, vp, i64, C.c_uint64, i64, vp, vp, vp, ci, cf, cf, vp, vp, ci, ci, ci, vp, ci, ci,
+                                          ci, vp]),
     "pmctf_fourstep_indexes_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp]),
     "pmctf_fourstep_dequant_f32": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "pmctf_mv_fourpart_indexes_f32": (ci, [vp, vp, vp, ci, ci, ci, cf, cf, vp]),

@@ -748,11 +748,19 @@ class _DecoderMixin:
         cur = torch.zeros(N, 1, H + 2, W + 2)
         bufs = {k: torch.zeros(N, nf, H + 2, W + 2) for k in ("r0c1", "r0c2", "r1c1", "r1c2", "m2")}
         w1, b1 = sd[p + ".maskedConv1.weight"], sd[p + ".maskedConv1.bias"]
-        conv = lambda x, name: self.K.conv2d(x, sd[name + ".weight"], sd[name + ".bias"])
+
+        def conv(x, name):
+            # PM-F32: the summation rule of the layer as the ENCODER's one-shot network ran it (on the whole N x H x W plane)
+            wt = sd[name + ".weight"]
+            if self.K.name == "cdef":
+                rule = self.sum_rule(name, torch.empty((N, wt.size(1), H, W), device="meta"), wt)
+                return self.K.conv2d(x, wt, sd[name + ".bias"], rule=rule)
+            return self.K.conv2d(x, wt, sd[name + ".bias"])
+
         for h in range(H):
             for w in range(W):
                 crop = cur[:, :, h:h + 3, w:w + 3]
-                tmp = self.K.conv2d(crop, w1, b1)
+                tmp = conv(crop, p + ".maskedConv1")
                 conv1 = tmp
                 for i in range(2):
                     q = f"{p}.residualBlocks.{i}"

@@ -121,6 +121,42 @@ def test_gop4_files_bits_psnr(setup):
     assert np.abs(np.array([p["yuv"] for p in ps]) - g["gop.psnr_yuv"]).max() < 1e-4
 
 
+def test_f32_aten_profile_equals_the_oracle_with_aten_all(cuda):
+    """precision "f32-aten" against the oracle's PM-F32 back-end with aten_all (the same rules layer for layer): files,
+    reconstructions and the decoder's output identical — the sequential LL decoder included, which has to run the rules
+    the encoder's one-shot LL network ran."""
+    import pmctf_gop
+    from pmctf_oracle.model import Oracle
+    net, sd = product_model(1)
+    net.precision = "f32-aten"
+    assert net.engine().aten_all
+    net.engine().keep_streams = True
+    orc = Oracle(sd, 1, "cdef", aten_all=True)
+    for (w, h, gop) in ((128, 128, 4), (200, 120, 2)):
+        fr = frames(w, h, gop)
+        frd = [[y.cuda(), c.cuda()] for y, c in fr]
+        with tempfile.TemporaryDirectory() as td, tempfile.TemporaryDirectory() as td2:
+            enc = pmctf_gop.encode_gop(net, frd, h, w, 3, td)
+            oenc = pmctf_gop.encode_gop(orc, fr, h, w, 3, td2)
+            for i, (r, o) in enumerate(zip(enc["results"], oenc["results"])):
+                for k in o["files"]:
+                    assert r["files"][k] == o["files"][k], f"{w}x{h} pair {i} file {k} differs"
+                for k in ("mv_hat", "H_t", "L_t", "H_tc", "L_tc"):
+                    assert_same(r[k], o[k], f"{w}x{h} pair {i} {k}")
+            rec = pmctf_gop.decode_gop(net, enc["frames_coded"])
+            orec = pmctf_gop.decode_gop(orc, oenc["frames_coded"])
+            for i in range(gop):
+                assert_same(rec[i][0], orec[i][0], f"rec {i} luma"); assert_same(rec[i][1], orec[i][1], f"rec {i} chroma")
+            # the real decoder from the files
+            dpb = {"mv_feature": None, "ref_mv_y": None}
+            e = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=w,
+                                     pic_height=h, skip_decoding=True, stage_idx=0, q_index=3)
+            d = net.encode_one_stage(frd[0], frd[1], True, dpb, output_path=os.path.join(td, "1.bin"), pic_width=w,
+                                     pic_height=h, skip_decoding=False, stage_idx=0, q_index=3)
+            for k in ("L_t", "H_t", "L_tc", "H_tc", "mv_hat"):
+                assert_same(d[k], e[k], f"decoded {k} vs encoder reconstruction")
+
+
 def test_decoder_round_trip_and_oracle(setup):
     """skip_decoding=False: bitstreams written by the HIP encoder are decoded by the HIP decoder (LL subband inside the
     persistent AR kernel) to exactly the encoder's reconstruction, and everything equals the oracle's decoder."""
@@ -491,14 +527,16 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1):
+def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, precision="f32"):
     import hashlib
     import pmctf_gop
-    key = (gop, q_index, sequence, size, me_downsample)
+    key = (gop, q_index, sequence, size, me_downsample, precision)
     if key in _headline_cache:
         return _headline_cache[key]
     g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample))
     net, _ = product_model(4)
+    net.precision = precision
+    assert net.engine().precision == precision
     net.engine().keep_streams = True
     w, h = size
     if sequence == "pan":
@@ -531,7 +569,7 @@ def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample
            "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
     print(f"{w}x{h} GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
           f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
-    d = os.environ.get("PMCTF_HEADLINE_REPORT")
+    d = os.environ.get("PMCTF_HEADLINE_REPORT") if precision == "f32" else None
     if d:       # builder's measuring run: collect what the pins file is written from
         import json
         os.makedirs(d, exist_ok=True)
@@ -572,6 +610,18 @@ def test_headline_configs_1080p_vs_reference(cuda, gop, q_index):
     assert r["bits_mv"] == r["ref_bits_mv"]
     assert r["psnr_err"] < 1e-4
     assert r["lengths_equal"]
+
+
+@pytest.mark.parametrize("gop,q_index", HEADLINE_CONFIGS, ids=[f"gop{g}-q{q}" for g, q in HEADLINE_CONFIGS])
+def test_f32_aten_profile_writes_the_reference_s_files(cuda, gop, q_index):
+    """precision "f32-aten" (ATen's summation order in every layer, the entropy-parameter networks included): at 1080p
+    every file of every configuration — motion, H and L pictures, luma and chroma — equals the file the REAL reference's
+    CPU run wrote, byte for byte (SHA-1 and length of each are in the digests), and the decoder of the same profile
+    reconstructs the frames to the reference's PSNR."""
+    r = _headline_run(gop, q_index, precision="f32-aten")
+    assert r["same"] == 3 * (gop - 1) + 2 and r["diff"] == 0, (r["same"], r["diff"])
+    assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
 
 
 @pytest.mark.parametrize("gop,q_index", HEADLINE_CONFIGS, ids=[f"gop{g}-q{q}" for g, q in HEADLINE_CONFIGS])

@@ -216,7 +216,10 @@ def test_resample_bitexact(cuda):
 @pytest.mark.parametrize("shape", [(1, 112, 44, 72, 112, 3, 1), (2, 64, 70, 100, 64, 3, 1), (1, 112, 264, 520, 112, 3, 1),
                                    (1, 16, 140, 150, 16, 3, 1),
                                    (1, 32, 48, 80, 64, 7, 1), (1, 64, 45, 70, 32, 7, 1), (2, 32, 37, 50, 16, 7, 1),
-                                   (1, 64, 64, 96, 128, 3, 2), (1, 192, 20, 36, 256, 1, 1)])
+                                   (1, 64, 64, 96, 128, 3, 2), (1, 192, 20, 36, 256, 1, 1),
+                                   # the shapes the block-sum variants of the specialised 3x3 kernels are launched on
+                                   (1, 112, 144, 240, 112, 3, 2), (1, 128, 40, 72, 128, 3, 1), (2, 32, 60, 100, 32, 3, 1),
+                                   (1, 112, 150, 250, 112, 3, 1), (1, 112, 36, 60, 112, 3, 1)])
 @pytest.mark.parametrize("rule", [0, 1], ids=["chain", "blocks"])
 def test_conv2d_launch_shapes_do_not_change_results(cuda, shape, rule):
     """Every way of cutting a convolution into workgroups (cout-tile split, row split, tile size, kernel variant)
@@ -336,6 +339,28 @@ def test_split_precision_conv_at_parity_class(cuda, shape):
                 assert torch.equal(y, ops.conv_at_class(conv, x, cls, act=ops.ACT_LEAKY, slope=0.2, res1=r1))
     finally:
         ops.SPLIT_MIN_PX = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 112, 144, 240), (2, 112, 44, 72), (1, 112, 30, 52)])
+def test_conv_at_parity_class_under_the_block_rule(cuda, shape):
+    """ops.conv_at_class with summation rule "blocks" (precision "f32-aten": the quarter-resolution context convolutions
+    follow ATen's order too): the same bits as the full convolution under that rule at the positions of the class,
+    whichever kernel the plane size selects (stride-2 pipelined kernel from 8 000 output pixels up, cout-split below)."""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    n, cin, h, w = shape
+    rng = _rng(h * w + 7)
+    wt = (rng.standard_normal((112, cin, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(112).astype(np.float32)
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    ref = clib.conv2d(x, wt, b, 1, (1, 1), 1)
+    conv = ops.Conv2d(torch.from_numpy(wt), torch.from_numpy(b), 1, (1, 1), rule=ops.SUM_BLOCKS)
+    xt = torch.from_numpy(x).permute(0, 2, 3, 1).contiguous().cuda()
+    for cls in range(4):
+        py, px = cls >> 1, cls & 1
+        y = ops.conv_at_class(conv, xt, cls).permute(0, 3, 1, 2).cpu().numpy()
+        assert_same(y, np.ascontiguousarray(ref[:, :, py::2, px::2]), f"class {cls}")
 
 
 @pytest.mark.gpu
