@@ -41,9 +41,18 @@ extern "C" {
  *                     chain starts at the bias, later blocks at zero, block results added in turn (B >= Cin is the chain).
  *                     What ATen's jit_1x1 kernel computes for the 1x1 layers whose reduction it blocks; B follows from the
  *                     layer's shape (pMCTF/hip/aten_rules.py, e.g. 256 -> 64 on a 576x960 plane: B = 96).
+ *   PMCTF_SUM_GEMM    (pmctf_conv2d_smallcin_f32 only) ONE chain from zero over (ci, ky, kx), bias added last: ATen's
+ *                     im2col + sgemm path, which it takes instead of oneDNN for a single image of at most 20 480 input
+ *                     elements and filters up to 3x3 (Convolution.cpp use_mkldnn).  With one input channel it equals BLOCKS.
  */
 #define PMCTF_SUM_CHAIN 0
 #define PMCTF_SUM_BLOCKS 1
+#define PMCTF_SUM_GEMM 2
+/* (pmctf_conv2d_smallcin_f32 only; Cin = 1, 3x3) the same path with ONE output channel is a matrix-vector product over the
+ * nine im2col columns p_k = x_k * w_k (k = 3 ky + kx); MKL's kernel sums eight at a time in four chains, the ninth after:
+ *   E = fma(p4, fma(p6, bias));  O = fma(p5, round(p7));  A = fma(p0, round(p2)) + fma(p1, round(p3));  y = fma(p8, (E + O) + A)
+ * (measured with probe inputs: tools/aten_gemv_probe.py; the 1 -> 1 "lower_level_subband" layer on planes <= 20 480 px) */
+#define PMCTF_SUM_GEMV_3X3 3
 
 #define PMCTF_ACT_NONE 0
 #define PMCTF_ACT_RELU 1    /* nn.ReLU                 video_net.py:77      */

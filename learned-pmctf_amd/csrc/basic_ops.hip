@@ -40,15 +40,48 @@ __global__ void conv_smallcin_kernel(const float *__restrict__ x, const float *_
         const int n = (int)(pm_div(p, Ho));
         const float bv = bias ? bias[co] : 0.0f;
         float acc = rule ? 0.0f : bv;            // rule 1 (one block, Cin <= 4): chain from zero, bias last
-        for (int ky = 0; ky < KH; ++ky) {
-            const int iy = oy * S + ky - ph;
-            if (iy < 0 || iy >= H) continue;
-            for (int kx = 0; kx < KW; ++kx) {
-                const int ix = ox * S + kx - pw;
-                if (ix < 0 || ix >= W) continue;
-                const float *xp = x + (((long)n * H + iy) * W + ix) * Cin;
-                const float *wp = wl + ((ky * KW + kx) * Cin) * Cout + co;
-                for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci * Cout], acc);
+        if (rule == PMCTF_SUM_GEMV_3X3) {        // Cin = 1, 3x3 (checked by the launcher): the order of include/pmctf_hip.h
+            float p[9];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = oy * S + ky - ph, ix = ox * S + kx - pw;
+                    p[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((long)n * H + iy) * W + ix] : 0.0f;
+                }
+            const float *wk = wl + co;           // [tap][ci = 0][co]
+            const float E = __builtin_fmaf(p[4], wk[4 * Cout], __builtin_fmaf(p[6], wk[6 * Cout], bv));
+            const float O = __builtin_fmaf(p[5], wk[5 * Cout], p[7] * wk[7 * Cout]);
+            const float Ae = __builtin_fmaf(p[0], wk[0], p[2] * wk[2 * Cout]);
+            const float Ao = __builtin_fmaf(p[1], wk[1 * Cout], p[3] * wk[3 * Cout]);
+            acc = __builtin_fmaf(p[8], wk[8 * Cout], (E + O) + (Ae + Ao));
+            float v = pm::apply_act(acc, act, slope);
+            if (res1) v = v + res1[idx];
+            if (res2) v = v + res2[idx];
+            y[idx] = v;
+            continue;
+        }
+        if (rule == PMCTF_SUM_GEMM) {            // im2col order: input channel outermost
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int ky = 0; ky < KH; ++ky) {
+                    const int iy = oy * S + ky - ph;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int kx = 0; kx < KW; ++kx) {
+                        const int ix = ox * S + kx - pw;
+                        if (ix < 0 || ix >= W) continue;
+                        acc = __builtin_fmaf(x[(((long)n * H + iy) * W + ix) * Cin + ci],
+                                             wl[((ky * KW + kx) * Cin + ci) * Cout + co], acc);
+                    }
+                }
+        } else {
+            for (int ky = 0; ky < KH; ++ky) {
+                const int iy = oy * S + ky - ph;
+                if (iy < 0 || iy >= H) continue;
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int ix = ox * S + kx - pw;
+                    if (ix < 0 || ix >= W) continue;
+                    const float *xp = x + (((long)n * H + iy) * W + ix) * Cin;
+                    const float *wp = wl + ((ky * KW + kx) * Cin) * Cout + co;
+                    for (int ci = 0; ci < Cin; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci * Cout], acc);
+                }
             }
         }
         if (rule) acc = acc + bv;
@@ -652,12 +685,15 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
                                          int KH, int KW, int stride, int pad_h, int pad_w, int act, float slope,
                                          int sum_rule, void *stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || KH <= 0 || KW <= 0 ||
-        stride <= 0 || (sum_rule != 0 && sum_rule != 1))
+        stride <= 0 || (sum_rule != PMCTF_SUM_CHAIN && sum_rule != PMCTF_SUM_BLOCKS && sum_rule != PMCTF_SUM_GEMM &&
+                        sum_rule != PMCTF_SUM_GEMV_3X3) ||
+        (sum_rule == PMCTF_SUM_GEMV_3X3 && (Cin != 1 || KH != 3 || KW != 3)))
         return PMCTF_EINVAL;
     const int rule = sum_rule;
     const int Ho = (H + 2 * pad_h - KH) / stride + 1, Wo = (W + 2 * pad_w - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return PMCTF_EINVAL;
-    if (KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 32 && Cout <= 256 &&
+    const bool gemm = rule == PMCTF_SUM_GEMM || rule == PMCTF_SUM_GEMV_3X3;   // small planes only (the rules' definition): the generic kernel
+    if (!gemm && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Cin <= 3 && Cout >= 32 && Cout <= 256 &&
         (Cout & 3) == 0) {
         const int Q = Cout / 4, G = 64 / Q;                    // lanes per pixel, strips per wave
         const int wstrips_per_row = (W + G * 8 - 1) / (G * 8);
@@ -675,7 +711,7 @@ extern "C" int pmctf_conv2d_smallcin_f32(const float *x, const float *w, const f
         if (Cin == 3) { PM_STRIP(3) }
 #undef PM_STRIP
     }
-    if (KH == KW && Cout <= 256 && (long)N * Ho * Wo < (1L << 31)) {
+    if (!gemm && KH == KW && Cout <= 256 && (long)N * Ho * Wo < (1L << 31)) {
         const int ppp = 256 / Cout;
         long nb = ((long)N * Ho * Wo + ppp - 1) / ppp;
         if (nb > 16384) nb = 16384;

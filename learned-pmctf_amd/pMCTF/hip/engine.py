@@ -344,13 +344,16 @@ class HipEngine:
         cout, cin, kh, kw = (int(v) for v in weight.shape)
         if not (self.aten_all or p.startswith(self.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return ops.SUM_CHAIN
+        tls = self._ref_tls
         if kh * kw > 1:
+            if self.aten_all and stride == 1 and ((1 < cin <= 4 and cout > 1) or (cin == 1 and cout == 1 and kh == 3 and kw == 3)):
+                # small-cin layers on small planes: ATen's im2col + sgemm order where it leaves oneDNN (aten_rules)
+                return lambda n, h, w: aten_rules.conv_kxk_sum_rule(cin, cout, kh, kw, getattr(tls, "planes", None) or n, h, w)
             return ops.SUM_BLOCKS
         if stride == 1 and (cin >= 112 or self.aten_all):
             # a 1x1 layer: ATen's jit_1x1 kernel cuts the reduction of wide layers into blocks on some plane sizes
             # (e.g. 256 -> 64 at 576x960: blocks of 96 channels); the rule follows from the shape of the REFERENCE's call
             # (its tensors hold one luma or two chroma planes, whatever batch this build has stacked)
-            tls = self._ref_tls
             return lambda n, h, w: aten_rules.conv1x1_sum_rule(cin, cout, getattr(tls, "planes", None) or n, h, w)
         return ops.SUM_CHAIN
 

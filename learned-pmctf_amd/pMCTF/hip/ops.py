@@ -16,7 +16,7 @@ import torch
 from . import lib as _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-SUM_CHAIN, SUM_BLOCKS = 0, 1        # PMCTF_SUM_* of include/pmctf_hip.h: the summation rule of a convolution
+SUM_CHAIN, SUM_BLOCKS, SUM_GEMM, SUM_GEMV_3X3 = 0, 1, 2, 3        # PMCTF_SUM_* of include/pmctf_hip.h: the summation rule of a convolution
 
 # Optional live timing of one conv signature with HIP events on the launch stream (bench.py: roofline of the
 # dominant kernel).  CONV_PROBE = {"match": fn(conv, x, stride) -> bool, "events": [(start, end, flops)]}

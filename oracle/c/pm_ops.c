@@ -138,6 +138,36 @@ static void pm_conv_job(long job, void *vctx) {
             }
             if (Cin > B)
                 for (int j = 0; j < PM_XB; ++j) acc[j] = tot[j] + acc[j];
+        } else if (c->rule == 3 && Cin == 1 && KH == 3 && KW == 3) {
+            /* "gemv 3x3": ATen's im2col + sgemm path with ONE output channel is a matrix-vector product over the nine im2col
+             * columns p_k = x_k * w_k (k = 3 * ky + kx), which MKL's kernel sums eight columns at a time in four chains and
+             * the ninth afterwards (order measured with probe inputs, tools/aten_gemv_probe.py):
+             *   E = fma(p4, fma(p6, bias));  O = fma(p5, round(p7));  A = fma(p0, round(p2)) + fma(p1, round(p3));
+             *   y = fma(p8, (E + O) + A) */
+            const float *r0 = xp + (((long)n * Hc + (long)oy * stride) * Cin) * Wc + (long)xb * stride;
+            const float *r1 = r0 + (long)Cin * Wc, *r2 = r1 + (long)Cin * Wc;
+            const float *wk = w + (long)co * 9;
+            for (int j = 0; j < PM_XB; ++j) {
+                const long o = (long)j * stride;
+                const float E = fmaf(r1[o + 1], wk[4], fmaf(r2[o], wk[6], b));
+                const float O = fmaf(r1[o + 2], wk[5], r2[o + 1] * wk[7]);
+                const float Ae = fmaf(r0[o], wk[0], r0[o + 2] * wk[2]);
+                const float Ao = fmaf(r0[o + 1], wk[1], r1[o] * wk[3]);
+                acc[j] = fmaf(r2[o + 2], wk[8], (E + O) + (Ae + Ao));
+            }
+        } else if (c->rule == 2) {
+            /* "gemm": ATen's im2col + sgemm path (a single image of at most 20 480 input elements, filters up to 3x3):
+             * ONE chain from zero over (ci, ky, kx) — the column order of im2col — and the bias added last */
+            for (int j = 0; j < PM_XB; ++j) acc[j] = 0.0f;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx) {
+                        const float wv = w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+                        const float *restrict row = xp + (((long)n * Hc + (long)oy * stride + ky) * Cin + ci) * Wc +
+                                                    (long)xb * stride + kx;
+                        for (int j = 0; j < PM_XB; ++j) acc[j] = fmaf(row[(long)j * stride], wv, acc[j]);
+                    }
+            for (int j = 0; j < PM_XB; ++j) acc[j] = acc[j] + b;
         } else if (c->rule == 1) {
             float tot[PM_XB];
             for (int c0 = 0; c0 < Cin; c0 += PM_CB) {

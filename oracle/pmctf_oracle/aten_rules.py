@@ -76,3 +76,18 @@ def conv1x1_sum_rule(cin, cout, n, h, w):
         return 1 if cin <= 16 else 0
     b = onednn_1x1_reduce_block(cin, cout, h, w)
     return b if b < cin and b % 16 == 0 else 0
+
+
+def conv_kxk_sum_rule(cin, cout, kh, kw, n, h, w):
+    """sum_rule argument of a KH*KW > 1 layer whose reference tensor is (n, cin, h, w): 1 = "blocks" (oneDNN's direct
+    convolution), or 2 = "gemm" where ATen leaves oneDNN (Convolution.cpp use_mkldnn: one image of at most 20 480 input
+    elements, a filter of at most 3 rows or columns) for im2col + sgemm — one chain from zero over (ci, ky, kx), bias last.
+    Restated for layers of up to 4 input channels (the small-cin kernels; with one channel both orders coincide) and for the
+    1 -> 1 3x3 layer (3 = "gemv 3x3"); wider layers meet the condition only on planes of a few hundred pixels and keep
+    "blocks"."""
+    if n == 1 and cin * h * w <= 20480 and (kh <= 3 or kw <= 3):
+        if 1 < cin <= 4 and cout > 1:
+            return 2
+        if cin == 1 and cout == 1 and kh == 3 and kw == 3:
+            return 3           # one output channel: sgemm degenerates to a matrix-vector product ("gemv 3x3", pmctf_hip.h)
+    return 1

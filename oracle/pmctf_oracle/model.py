@@ -101,6 +101,8 @@ class Oracle:
             return 0
         if w.size(0) == 1 and w.size(1) == 1 and w.size(3) == 1 and x.size(0) == 1 and x.numel() <= 20480:
             return 0
+        if self.aten_all and stride == 1:
+            return aten_rules.conv_kxk_sum_rule(w.size(1), w.size(0), w.size(2), w.size(3), x.size(0), x.size(2), x.size(3))
         return 1
 
     def conv(self, p, x, stride=1, padding=0, groups=1):

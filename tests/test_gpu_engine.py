@@ -729,6 +729,23 @@ def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
     assert r["lengths_equal"]
 
 
+_ATEN_OTHER = [c for c in ((8, 3, "layers", (1920, 1080), 1), (16, 3, "layers", (1920, 1080), 1), (8, 3, "pan", (1366, 768), 1),
+                            (2, 3, "layers", (3840, 2160), 1), (8, 3, "pan", (1920, 1080), 2))
+               if os.path.exists(_digest_path(c[0], c[1], c[2], c[3], c[4]))]
+
+
+@pytest.mark.parametrize("gop,q_index,sequence,size,ds", _ATEN_OTHER,
+                         ids=[f"gop{c[0]}-{c[2]}-{c[3][0]}x{c[3][1]}-ds{c[4]}" for c in _ATEN_OTHER])
+def test_f32_aten_profile_other_sequences_and_sizes(cuda, gop, q_index, sequence, size, ds):
+    """precision "f32-aten" on the other reference configurations that have digests — the second sequence (occlusion),
+    1366x768 (planes small enough that ATen leaves oneDNN for some layers: the "gemm" / "gemv 3x3" rules), a 3840x2160
+    pair, motion at half resolution: every file byte-identical to the reference's, PSNR within 1e-4 dB."""
+    r = _headline_run(gop, q_index, sequence, size, ds, precision="f32-aten")
+    assert r["diff"] == 0 and r["same"] == 3 * (gop - 1) + 2, (r["same"], r["diff"])
+    assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+
+
 def test_gop_with_reduced_resolution_motion(setup):
     """The content-adaptive harness's GOP schedule (test_pMCTF_CA.py:code_one_gop) with me_downsample=2: a GOP of 4
     through the same loop on the product and on the oracle — identical bits, files and reconstruction."""

@@ -342,6 +342,28 @@ def test_split_precision_conv_at_parity_class(cuda, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 3, 3, 3, 48, 88, 2), (1, 2, 112, 3, 37, 53, 2), (1, 4, 16, 3, 20, 36, 2), (2, 3, 3, 3, 17, 40, 2),
+                                  (1, 1, 1, 3, 96, 176, 3), (1, 1, 1, 3, 33, 47, 3), (2, 1, 1, 3, 20, 30, 3)])
+def test_small_plane_rules_bitexact(cuda, case):
+    """PMCTF_SUM_GEMM / PMCTF_SUM_GEMV_3X3 (the orders of ATen's im2col + sgemm path on small planes, include/pmctf_hip.h) in
+    the small-cin kernel against the oracle's restatement, with activation and residual"""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    n, cin, cout, k, h, w, rule = case
+    rng = _rng(h * w + cin)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r1 = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+    ref = clib.conv2d(x, wt, b, 1, (k // 2, k // 2), rule)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.2)).astype(np.float32) + r1
+    conv = ops.Conv2d(torch.from_numpy(wt), torch.from_numpy(b), 1, (k // 2, k // 2), rule=rule)
+    y = conv(torch.from_numpy(x).permute(0, 2, 3, 1).contiguous().cuda(), act=ops.ACT_LEAKY, slope=0.2,
+             res1=torch.from_numpy(r1).permute(0, 2, 3, 1).contiguous().cuda())
+    assert_same(y.permute(0, 3, 1, 2).cpu().numpy(), ref, f"rule {rule}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 112, 144, 240), (2, 112, 44, 72), (1, 112, 30, 52)])
 def test_conv_at_parity_class_under_the_block_rule(cuda, shape):
     """ops.conv_at_class with summation rule "blocks" (precision "f32-aten": the quarter-resolution context convolutions

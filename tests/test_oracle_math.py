@@ -125,6 +125,32 @@ def test_signal_path_convolutions_are_aten_s_bit_for_bit():
         assert same, (n, cin, h, w, cout, kh, kw, s, rule)
 
 
+def test_small_plane_rules_are_aten_s_bit_for_bit():
+    """Where ATen leaves oneDNN (one image of at most 20 480 input elements, filters up to 3x3) it runs im2col + sgemm:
+    rule "gemm" (oracle/c/pm_ops.c rule 2) for small-cin layers, "gemv 3x3" (rule 3) for the 1 -> 1 layer, and for 1x1
+    layers of up to 16 input channels the chain from zero (rule 1).  Checked live against F.conv2d on this machine when its
+    ATen is the fixtures' (the oneDNN probe of the test above), with the shape rule choosing (aten_rules)."""
+    import pytest
+    from pmctf_oracle import aten_rules, clib
+    g = torch.Generator().manual_seed(9)
+    probe_x, probe_w, probe_b = torch.randn(1, 16, 72, 120, generator=g), torch.randn(16, 16, 3, 3, generator=g) * .05, torch.randn(16, generator=g)
+    if not np.array_equal(clib.conv2d(probe_x.numpy(), probe_w.numpy(), probe_b.numpy(), 1, (1, 1), 1).view(np.uint32),
+                          F.conv2d(probe_x, probe_w, probe_b, padding=1).numpy().view(np.uint32)):
+        pytest.skip("this machine's ATen convolution is not the fixtures' (other oneDNN ISA path)")
+    for (n, cin, cout, k, h, w, want) in [(1, 3, 3, 3, 48, 88, 2), (1, 2, 112, 3, 48, 88, 2), (1, 3, 3, 3, 96, 176, 1),
+                                          (2, 3, 3, 3, 24, 44, 1), (1, 1, 1, 3, 96, 176, 3), (1, 1, 1, 3, 40, 64, 3),
+                                          (1, 1, 1, 3, 144, 240, 1), (2, 1, 1, 3, 48, 88, 1), (1, 1, 32, 3, 48, 88, 1),
+                                          (1, 2, 8, 1, 72, 120, 1), (2, 2, 8, 1, 36, 60, 0)]:
+        x = torch.randn(n, cin, h, w, generator=g) * 2
+        wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
+        b = torch.randn(cout, generator=g)
+        rule = aten_rules.conv1x1_sum_rule(cin, cout, n, h, w) if k == 1 else aten_rules.conv_kxk_sum_rule(cin, cout, k, k, n, h, w)
+        assert rule == want, (n, cin, cout, k, h, w, rule)
+        ref = F.conv2d(x, wt, b, padding=k // 2).numpy()
+        y = clib.conv2d(x.numpy(), wt.numpy(), b.numpy(), 1, (k // 2, k // 2), rule)
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (n, cin, cout, k, h, w, rule)
+
+
 def test_aten_rule_predictor_has_one_definition():
     """the product carries its own copy of the shape rule (pMCTF/hip/aten_rules.py); it must equal the oracle's"""
     import itertools
@@ -135,5 +161,7 @@ def test_aten_rule_predictor_has_one_definition():
                                                 (48, 88), (96, 176), (192, 352), (16, 32), (32, 64), (64, 128), (27, 48),
                                                 (28, 48), (10, 300), (11, 300), (1088, 1920))):
         assert a.conv1x1_sum_rule(cin, cout, 1, h, w) == b.conv1x1_sum_rule(cin, cout, 1, h, w)
+    for cin, cout, k, n, (h, w) in itertools.product((1, 2, 3, 4, 16), (1, 3, 112), (3, 7), (1, 2), ((48, 88), (96, 176), (144, 240))):
+        assert a.conv_kxk_sum_rule(cin, cout, k, k, n, h, w) == b.conv_kxk_sum_rule(cin, cout, k, k, n, h, w)
     assert a.onednn_1x1_reduce_block(256, 64, 576, 960) == 96 and a.onednn_1x1_reduce_block(768, 192, 72, 120) == 512
     assert a.onednn_1x1_reduce_block(192, 192, 16, 32) == 80 and a.onednn_1x1_reduce_block(256, 64, 144, 240) == 256
