@@ -267,6 +267,12 @@ int pmctf_ffn3_mix_f32(const float *x, float *y, int64_t P, int C, void *stream)
 /* LSTM2D gates (long_context.py:20-33); xh = conv_in(x)+conv_hidden(h), NHWC [P,C]; cell [P,Ccell], Ccell in {1,C} */
 int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P, int C,
                          int Ccell, void *stream);
+/* The same with torch.sigmoid as ATen evaluates it on the reference's contiguous (ref_planes, C, H, W) gate tensor with
+ * aten_threads intra-op threads: whole strides of 32 floats of a thread's slice through SLEEF, the rest of the slice
+ * through libm's expf (pm_glibc_expf.h).  HW = H * W; xh holds P / HW planes, ref_planes per reference tensor.
+ * aten_threads = 0: no tails (= pmctf_lstm_gates_f32). */
+int pmctf_lstm_gates_aten_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P, int C,
+                              int Ccell, int64_t HW, int ref_planes, int aten_threads, void *stream);
 
 /* ---- quantisation + symbol hand-off --------------------------------
  * sym/idx receive one full-size push (int16 symbol, int16 CDF row) in the reference's flattening order

@@ -270,8 +270,10 @@ __global__ void ffn3_mix_kernel(const float *__restrict__ x, float *y, long P, i
 }
 
 // LSTM2D gates (long_context.py:20-33): f = sigmoid(xh); cell' = f*cell + f*tanh(xh); hidden' = f*tanh(cell')
+// aten_threads > 0: the gate tensor is the reference's contiguous (ref_planes, C, H, W) tensor evaluated by ATen with that
+// many intra-op threads — the scalar tail of every thread's slice takes libm's expf (pm_glibc_expf.h)
 __global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__restrict__ cell, float *cell_out,
-                                  float *hid_out, long P, int C, int Cc) {
+                                  float *hid_out, long P, int C, int Cc, long HW, int ref_planes, int aten_threads) {
     __shared__ uint4 tanh_tab[pm::TANH_LDS_UINT4];
     pm::tanh_rows_to_lds(tanh_tab, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -280,7 +282,15 @@ __global__ void lstm_gates_kernel(const float *__restrict__ xh, const float *__r
         const int c = (int)(pm_mod(idx, C));
         const long p = pm_div(idx, C);
         const float v = xh[idx];
-        const float g = pm::sigmoidf_(v);
+        float g;
+        if (aten_threads > 0) {
+            const long n = pm_div(p, HW), hw = p - n * HW;
+            const long ref_idx = ((n % ref_planes) * C + c) * HW + hw;        // NCHW index inside the reference's tensor
+            g = pm_aten_sigmoid_tail(ref_idx, (long)ref_planes * C * HW, aten_threads) ? pm_aten_sigmoidf_scalar(v)
+                                                                                       : pm::sigmoidf_(v);
+        } else {
+            g = pm::sigmoidf_(v);
+        }
         const float ct = pm::tanhf_rows(v, tanh_tab);
         const float cprev = cell[p * Cc + (Cc == 1 ? 0 : c)];
         const float t1 = g * cprev;
@@ -528,9 +538,16 @@ extern "C" int pmctf_ffn3_mix_f32(const float *x, float *y, int64_t P, int C, vo
 
 extern "C" int pmctf_lstm_gates_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P,
                                     int C, int Ccell, void *stream) {
-    if (!xh || !cell || !cell_out || !hid_out || P <= 0 || C <= 0 || (Ccell != 1 && Ccell != C)) return PMCTF_EINVAL;
+    return pmctf_lstm_gates_aten_f32(xh, cell, cell_out, hid_out, P, C, Ccell, P, 1, 0, stream);
+}
+
+extern "C" int pmctf_lstm_gates_aten_f32(const float *xh, const float *cell, float *cell_out, float *hid_out, int64_t P,
+                                         int C, int Ccell, int64_t HW, int ref_planes, int aten_threads, void *stream) {
+    if (!xh || !cell || !cell_out || !hid_out || P <= 0 || C <= 0 || (Ccell != 1 && Ccell != C) || aten_threads < 0 ||
+        (aten_threads > 0 && (HW <= 0 || ref_planes <= 0 || P % HW || (P / HW) % ref_planes)))
+        return PMCTF_EINVAL;
     PM_LAUNCH(lstm_gates_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, xh, cell, cell_out,
-                       hid_out, (long)P, C, Ccell);
+                       hid_out, (long)P, C, Ccell, (long)HW, ref_planes, aten_threads);
     return launch_ok();
 }
 

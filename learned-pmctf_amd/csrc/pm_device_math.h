@@ -10,6 +10,8 @@
 #include "pm_log_tables.h"
 #define PM_SLEEF_FN __device__ __forceinline__
 #include "pm_sleef_f32.h"
+#define PM_GLIBC_FN __device__ __forceinline__
+#include "pm_glibc_expf.h"
 
 namespace pm {
 

@@ -240,6 +240,9 @@ class HipEngine:
         self.precision = precision
         self.nsplit = self.PRECISIONS[precision]
         self.aten_all = precision == "f32-aten"
+        # "f32-aten" also follows ATen's split of torch.sigmoid over its intra-op threads (the scalar tails of the threads'
+        # slices go through libm's expf): 8 threads, the machine the fixtures under tests/golden were generated on
+        self.aten_threads = int(os.environ.get("PMCTF_ATEN_THREADS", "8"))
         if not torch.cuda.is_available():
             raise RuntimeError("pMCTF HIP engine needs a GPU: the product path has no CPU fallback")
         _lib.hip()
@@ -801,7 +804,8 @@ class HipEngine:
     def lstm(self, p, x, state):
         a = self.conv(p + ".conv_in", 1, 1)(x)
         xh = self.conv(p + ".conv_hidden", 1, 1)(state[0], res1=a)
-        hid, cell = ops.lstm_gates(xh, state[1])
+        hid, cell = ops.lstm_gates(xh, state[1], getattr(self._ref_tls, "planes", None),
+                                   self.aten_threads if self.aten_all else 0)
         return [hid, cell]
 
     def ctx_init(self, N, H, W):

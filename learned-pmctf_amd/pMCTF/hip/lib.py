@@ -56,6 +56,7 @@ _SIGS = {
     "pmctf_pixel_shuffle2_nhwc_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, cf, vp]),
     "pmctf_ffn3_mix_f32": (ci, [vp, vp, i64, ci, vp]),
     "pmctf_lstm_gates_f32": (ci, [vp, vp, vp, vp, i64, ci, ci, vp]),
+    "pmctf_lstm_gates_aten_f32": (ci, [vp, vp, vp, vp, i64, ci, ci, i64, ci, ci, vp]),
     "pmctf_fourstep_quant_f32": (ci, [vp] * 5 + [ci, ci, ci, ci, ci, cf, cf, vp]),
     "pmctf_ll_quant_f32": (ci, [vp] * 5 + [i64, ci, cf, cf, vp]),
     "pmctf_ll_ar_packed_size": (i64, []),

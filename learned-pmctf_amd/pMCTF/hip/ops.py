@@ -346,11 +346,14 @@ def ffn3_mix(x):
     return y
 
 
-def lstm_gates(xh, cell):
+def lstm_gates(xh, cell, ref_planes=None, aten_threads=0):
+    """aten_threads > 0: torch.sigmoid as ATen splits the reference's (ref_planes, C, H, W) gate tensor over that many
+    threads (include/pmctf_hip.h pmctf_lstm_gates_aten_f32); ref_planes defaults to the batch of xh"""
     N, H, W, Cc = xh.shape
     cell_out, hid_out = torch.empty_like(xh), torch.empty_like(xh)
-    _lib.check(_lib.hip().pmctf_lstm_gates_f32(_p(xh), _p(cell), _p(cell_out), _p(hid_out), N * H * W, Cc,
-                                               cell.shape[3], _stream()), "lstm_gates")
+    _lib.check(_lib.hip().pmctf_lstm_gates_aten_f32(_p(xh), _p(cell), _p(cell_out), _p(hid_out), N * H * W, Cc,
+                                                    cell.shape[3], H * W, int(ref_planes or N), int(aten_threads),
+                                                    _stream()), "lstm_gates")
     return hid_out, cell_out
 
 

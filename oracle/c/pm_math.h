@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "pm_sleef_f32.h"
+#include "pm_glibc_expf.h"
 
 static inline float pm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t pm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

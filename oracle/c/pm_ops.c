@@ -285,6 +285,12 @@ void pm_tanh_arr(const float *x, float *y, long n) {
 void pm_sigmoid_arr(const float *x, float *y, long n) {
     for (long i = 0; i < n; ++i) y[i] = pm_sigmoidf(x[i]);
 }
+/* torch.sigmoid of a contiguous tensor as ATen evaluates it with `threads` intra-op threads: SLEEF on whole strides of 32
+ * floats of every thread's slice, libm's expf on the rest of a slice (pm_glibc_expf.h) */
+void pm_sigmoid_aten_arr(const float *x, float *y, long n, int threads) {
+    for (long i = 0; i < n; ++i)
+        y[i] = (threads > 0 && pm_aten_sigmoid_tail(i, n, threads)) ? pm_aten_sigmoidf_scalar(x[i]) : pm_sigmoidf(x[i]);
+}
 void pm_log_arr(const float *x, float *y, long n) {
     for (long i = 0; i < n; ++i) y[i] = pm_logf(x[i]);
 }

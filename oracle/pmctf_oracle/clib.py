@@ -37,6 +37,7 @@ def lib():
     L.pm_dwconv2d.argtypes = [f32p, f32p, C.c_void_p, f32p] + [C.c_int] * 5
     for n in ("pm_tanh_arr", "pm_sigmoid_arr", "pm_log_arr", "pm_exp_arr"):
         getattr(L, n).argtypes = [f32p, f32p, C.c_long]
+    L.pm_sigmoid_aten_arr.argtypes = [f32p, f32p, C.c_long, C.c_int]
     L.pm_flow_warp.argtypes = [f32p, f32p, f32p, f32p, f32p] + [C.c_int] * 5
     for n in ("pm_avgpool2", "pm_bilinear_up2", "pm_bilinear_down2"):
         getattr(L, n).argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
@@ -121,8 +122,15 @@ def tanh(x):
     return _map("pm_tanh_arr", x)
 
 
-def sigmoid(x):
-    return _map("pm_sigmoid_arr", x)
+def sigmoid(x, aten_threads=0):
+    """aten_threads > 0: x is one contiguous tensor as ATen evaluates it with that many intra-op threads (the scalar tail
+    of every thread's slice goes through libm's expf: oracle/c/pm_glibc_expf.h)"""
+    if not aten_threads:
+        return _map("pm_sigmoid_arr", x)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().pm_sigmoid_aten_arr(x.reshape(-1), y.reshape(-1), x.size, int(aten_threads))
+    return y
 
 
 def log(x):

@@ -35,6 +35,8 @@ class TorchK:
     def sigmoid(self, x):
         return torch.sigmoid(x)
 
+    sigmoid_plain = sigmoid
+
     def lin_tables(self, H, W):
         return torch.linspace(-1.0, 1.0, W), torch.linspace(-1.0, 1.0, H)
 
@@ -109,8 +111,13 @@ class CdefK(TorchK):
     def tanh(self, x):
         return _t(clib.tanh(x.numpy()))
 
+    aten_threads = 0       # > 0: torch.sigmoid with that many intra-op threads (scalar tails of the threads' slices)
+
     def sigmoid(self, x):
-        return _t(clib.sigmoid(x.numpy()))
+        return _t(clib.sigmoid(x.contiguous().numpy(), self.aten_threads))
+
+    def sigmoid_plain(self, x):
+        return _t(clib.sigmoid(x.contiguous().numpy()))
 
     def flow_warp(self, im, flow):
         N, _, H, W = im.shape
@@ -150,7 +157,7 @@ class CdefK(TorchK):
             x = x * sp_h + b
             if th_a is not None:
                 x = x + self.tanh(x.contiguous()) * th_a
-        return self.sigmoid(x.contiguous())
+        return self.sigmoid_plain(x.contiguous())     # rate estimate only: no claim on the threads' scalar tails
 
     def z_bits(self, z, params):
         return self._neglog2(self.bitparm_cdf(z + 0.5, params) - self.bitparm_cdf(z - 0.5, params))

@@ -95,6 +95,28 @@ def test_sigmoid_is_the_reference_s_bit_for_bit():
         open(os.path.join(root, "learned-pmctf_amd", "csrc", "pm_sleef_f32.h")).read()
 
 
+def test_sigmoid_scalar_tails_of_the_threads_slices():
+    """ATen splits an elementwise op over its intra-op threads and evaluates the last numel % 32 elements of every slice
+    with the scalar lambda (libm's expf instead of SLEEF's): clib.sigmoid(x, aten_threads) restates the split
+    (oracle/c/pm_glibc_expf.h).  Against torch.sigmoid with the same thread count on the gate tensor of the path that has
+    such tails (two chroma planes, 3 channels, 144x240: seven slices of 29 623), and on one that has none."""
+    from pmctf_oracle import clib
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden",
+                                           "reference_torch_sigmoid.npz"))
+    if not np.array_equal(torch.sigmoid(torch.from_numpy(g["sigmoid_x"])).numpy().view(np.uint32), g["sigmoid_y"].view(np.uint32)):
+        import pytest
+        pytest.skip("this machine's torch.sigmoid is not the fixtures'")
+    t = torch.get_num_threads()
+    gen = torch.Generator().manual_seed(3)
+    for shape in ((2, 3, 144, 240), (1, 3, 144, 240), (2, 32, 36, 60), (1, 7, 33, 41)):
+        x = torch.randn(shape, generator=gen) * 3
+        ref = torch.sigmoid(x).numpy()
+        assert np.array_equal(clib.sigmoid(x.numpy(), t).view(np.uint32), ref.view(np.uint32)), shape
+    if t == 8:
+        x = torch.randn((2, 3, 144, 240), generator=gen) * 3
+        assert not np.array_equal(clib.sigmoid(x.numpy()).view(np.uint32), torch.sigmoid(x).numpy().view(np.uint32))
+
+
 def test_signal_path_convolutions_are_aten_s_bit_for_bit():
     """The summation rules of the signal path (oracle/c/pm_ops.c rule 1 for KH*KW > 1, the chain or oneDNN's blocked
     reduction for 1x1: pmctf_oracle.aten_rules) reproduce F.conv2d bit for bit on the layer shapes of the path — checked
