@@ -223,25 +223,29 @@ class CaptureGate:
 
 
 class HipEngine:
-    PRECISIONS = {"f32": 0, "f32-aten": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
+    PRECISIONS = {"f32": 0, "f32-chain": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
 
     def __init__(self, state_dict, num_me_stages, device, gaussian_tables, bit_est_tables, decomp_levels=4,
                  coder_threads=4, precision="f32"):
-        """precision: "f32" = PM-F32, the product's arithmetic (bit-exact against the oracle).  "f32-aten": PM-F32 with
-        ATen's summation order in EVERY layer, the entropy-parameter networks included (sum_rule): what the reference's
-        CPU path computes, to the bit, on frames whose planes ATen evaluates through oneDNN — the written files then equal
-        the reference's byte for byte and its files decode (a few percent slower: aten_all).  "bf16x3" / "bf16x2" /
-        "bf16": the AUXILIARY reduced-precision profile — the dense 3x3 convolutions with 64 / 112 couts on planes of at
-        least ops.SPLIT_MIN_PX pixels run on bf16 MFMA with operands split into 3 / 2 / 1 planes (conv_split.hip); every
-        other kernel is unchanged.  Encoder and decoder built with the same profile agree bit for bit; results differ
-        from PM-F32 in the last bits, so no parity claim is made for it."""
+        """precision: "f32" = PM-F32, the product's arithmetic: bit-exact against the oracle, and ATen's summation order
+        in EVERY layer (sum_rule) plus ATen's thread split of torch.sigmoid — what the reference's CPU path computes, to
+        the bit, on frames whose planes ATen evaluates through oneDNN or its small-plane sgemm path: the written files
+        equal the reference's byte for byte and its files decode.
+        "f32-chain": the entropy-parameter networks (context fusion, LL network, conv-LSTM) keep one chain from the bias
+        instead (their dominant kernel then needs no second accumulator set: ~5 % faster); coefficients and motion are
+        still the reference's, but a CDF row flips now and then, so a few files differ in bytes and, rarely, a stream
+        moves by a 32-bit word.  No parity claim beyond that.
+        "bf16x3" / "bf16x2" / "bf16": the AUXILIARY reduced-precision profile — the dense 3x3 convolutions with 64 / 112
+        couts on planes of at least ops.SPLIT_MIN_PX pixels run on bf16 MFMA with operands split into 3 / 2 / 1 planes
+        (conv_split.hip; the other layers as in "f32-chain").  Encoder and decoder built with the same profile agree bit
+        for bit; results differ from PM-F32 in the last bits, so no parity claim is made for it."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self.precision = precision
         self.nsplit = self.PRECISIONS[precision]
-        self.aten_all = precision == "f32-aten"
-        # "f32-aten" also follows ATen's split of torch.sigmoid over its intra-op threads (the scalar tails of the threads'
-        # slices go through libm's expf): 8 threads, the machine the fixtures under tests/golden were generated on
+        self.aten_all = precision == "f32"
+        # ... including ATen's split of torch.sigmoid over its intra-op threads (the scalar tails of the threads' slices go
+        # through libm's expf): 8 threads, the machine the fixtures under tests/golden were generated on
         self.aten_threads = int(os.environ.get("PMCTF_ATEN_THREADS", "8"))
         if not torch.cuda.is_available():
             raise RuntimeError("pMCTF HIP engine needs a GPU: the product path has no CPU fallback")
@@ -341,9 +345,9 @@ class HipEngine:
         first): measured, the last bits of exactly these layers decide the symbols that differed from the reference's
         (profiles/round4_flip_attribution.md).  1x1 layers follow the chain from the bias, which IS ATen's order — except
         where ATen blocks a 1x1 layer's reduction or leaves oneDNN (aten_rules).
-        The entropy-parameter networks keep the single chain from the bias in the default profile (their last bits move
-        a CDF row now and then, not a coefficient: same sizes, a few files differ in bytes); with precision "f32-aten"
-        they follow ATen's order like the signal path."""
+        The entropy-parameter networks follow ATen's order like the signal path; with precision "f32-chain" (and the
+        reduced-precision profiles) they keep the single chain from the bias (their last bits move a CDF row now and then,
+        not a coefficient)."""
         cout, cin, kh, kw = (int(v) for v in weight.shape)
         if not (self.aten_all or p.startswith(self.SIGNAL_PATH) or ".wavelet_transform." in p or ".dequantModule." in p):
             return ops.SUM_CHAIN

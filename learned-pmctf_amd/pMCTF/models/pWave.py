@@ -5,6 +5,8 @@ In this implementation pWave is the owner of one coder's parameters; the numeric
 driven from pMCTF.encode_one_stage.  A standalone pWave can still compress a plane through its own
 engine (`compress`), mirroring pWave.compress(x, sideinfo, file_name, q_index, skip_decoding, qp_scale).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -72,7 +74,8 @@ class pWave(nn.Module):
                 raise RuntimeError("call update(force=True) before coding")
             g = {"cdf_info": ge.get_cdf_info(), "log_scale_min": ge.log_scale_min, "log_scale_step": ge.log_scale_step}
             sd = {"coder." + k: v for k, v in self.state_dict().items()}
-            self._engine = HipEngine(sd, 0, dev, g, [], decomp_levels=self.decomp_levels)
+            self._engine = HipEngine(sd, 0, dev, g, [], decomp_levels=self.decomp_levels,
+                                     precision=getattr(self, "precision", None) or os.environ.get("PMCTF_PRECISION", "f32"))
         return self._engine
 
     @torch.no_grad()

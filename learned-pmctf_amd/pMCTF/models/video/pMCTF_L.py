@@ -118,7 +118,8 @@ class pMCTF(nn.Module):
         # (pMCTF.hip.deferred).  Off by default: the reference harness formats a bit count after every call
         # (test_pMCTF_flex.py:240,248), which forces every pair at once, and its log step needs plain numbers
         # (video_eval_utils.py:86-133) — the default returns finished tensors and Python floats, call by call.
-        # arithmetic profile of the engine: "f32" (PM-F32, the parity path) or the auxiliary reduced-precision profiles
+        # arithmetic profile of the engine: "f32" (PM-F32, the parity path), "f32-chain" (faster, approximate entropy
+        # parameters) or the auxiliary reduced-precision profiles
         # "bf16x3" / "bf16x2" / "bf16" (HipEngine docstring); set before the first encode, or call update(force=True)
         self.precision = os.environ.get("PMCTF_PRECISION", "f32")
         self.lazy_stages = os.environ.get("PMCTF_LAZY", "0") == "1"

@@ -57,9 +57,11 @@ def get_curr_q(q_scale, q_index):
 
 
 class Oracle:
-    def __init__(self, state_dict, num_me_stages=1, backend="cdef", decomp_levels=4, aten_all=False, aten_threads=8):
+    def __init__(self, state_dict, num_me_stages=1, backend="cdef", decomp_levels=4, aten_all=None, aten_threads=8):
         self.K = CdefK() if backend == "cdef" else TorchK()
-        self.aten_all = aten_all   # PM-F32 back-end: ATen's summation order in every layer (the product's "f32-aten")
+        if aten_all is None:       # follow the profile the product's models take from the environment (PMCTF_PRECISION)
+            aten_all = os.environ.get("PMCTF_PRECISION", "f32") == "f32"
+        self.aten_all = aten_all   # PM-F32 back-end: ATen's summation order in every layer (False: the product's "f32-chain")
         if aten_all and backend == "cdef":
             # ... and ATen's split of an elementwise op over its intra-op threads (8 on the machine the fixtures under
             # tests/golden were generated on): torch.sigmoid's scalar tails (oracle/c/pm_glibc_expf.h)

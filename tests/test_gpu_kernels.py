@@ -366,7 +366,7 @@ def test_small_plane_rules_bitexact(cuda, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 112, 144, 240), (2, 112, 44, 72), (1, 112, 30, 52)])
 def test_conv_at_parity_class_under_the_block_rule(cuda, shape):
-    """ops.conv_at_class with summation rule "blocks" (precision "f32-aten": the quarter-resolution context convolutions
+    """ops.conv_at_class with summation rule "blocks" (the quarter-resolution context convolutions
     follow ATen's order too): the same bits as the full convolution under that rule at the positions of the class,
     whichever kernel the plane size selects (stride-2 pipelined kernel from 8 000 output pixels up, cout-split below)."""
     from pmctf_oracle import clib

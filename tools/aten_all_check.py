@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The spatial coder of ONE picture through the oracle's two back-ends: ATen (what the reference computes) and PM-F32 with
-ATen's summation order in every layer (aten_all = the product's precision "f32-aten").  The two must write the same
+ATen's summation order in every layer (aten_all = the product's precision "f32").  The two must write the same
 bytes.  CPU only (test infrastructure).   usage: aten_all_check.py [WxH] [luma|chroma] [q_index] [H|L]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

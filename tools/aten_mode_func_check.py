@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Function-level HIP ("f32-aten") vs oracle (PM-F32, aten_all) comparison of the entropy-parameter networks. GPU tool."""
+"""Function-level HIP ("f32") vs oracle (PM-F32, aten_all) comparison of the entropy-parameter networks. GPU tool."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("learned-pmctf_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-os.environ["PMCTF_PRECISION"] = sys.argv[1] if len(sys.argv) > 1 else "f32-aten"
+os.environ["PMCTF_PRECISION"] = sys.argv[1] if len(sys.argv) > 1 else "f32"
 import numpy as np, torch
 from helpers import product_model
 from pmctf_oracle.model import Oracle

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""HIP engine with precision "f32-aten" vs the oracle's PM-F32 back-end with aten_all, picture by picture (spatial coder
+"""HIP engine with precision "f32" vs the oracle's PM-F32 back-end with aten_all, picture by picture (spatial coder
 only): symbols, CDF rows, bytes and the reconstruction must be identical.  GPU tool.  usage: [WxH] [q]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("learned-pmctf_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-os.environ["PMCTF_PRECISION"] = "f32" if "--default" in sys.argv else "f32-aten"
+os.environ["PMCTF_PRECISION"] = "f32-chain" if "--chain" in sys.argv else "f32"
 import numpy as np, torch
 from helpers import frames, product_model
 from pmctf_oracle.model import Oracle, get_curr_q

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Every convolution layer of the spatial coder (by parameter key) on random input: the HIP engine's launch with the rule
-precision "f32-aten" gives the layer vs the oracle's C convolution with the oracle's rule for it.  GPU tool."""
+precision "f32" gives the layer vs the oracle's C convolution with the oracle's rule for it.  GPU tool."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("learned-pmctf_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-os.environ["PMCTF_PRECISION"] = "f32-aten"
+os.environ["PMCTF_PRECISION"] = "f32"
 import numpy as np, torch
 from helpers import product_model
 from pmctf_oracle import clib
