@@ -510,7 +510,9 @@ _Pragma("unroll")
 // MT x 4 quads do not fit 256 registers at MT = 7: that instantiation runs ONE workgroup per CU (512 registers per lane, the
 // compiler keeps one set in AGPRs); the rule-0 instantiation measured the same 137 TFLOP/s at one workgroup per CU
 // (docs/history.md section 9), i.e. the kernel is MFMA-bound, not occupancy-bound.
-template <int MT, int NBUF, bool BSUM = false>
+// MOFF >= 0: the workgroup takes MT cout tiles starting at tile MOFF of packed M-block blockIdx.z (a 7-tile block run as
+// 4 + 3 tiles in two launches: both accumulator sets of rule "blocks" then fit 256 registers at two workgroups per CU).
+template <int MT, int NBUF, bool BSUM = false, int MOFF = -1>
 __global__ __launch_bounds__(256, (BSUM && MT >= 7) ? 1 : (NBUF == 1 ? 3 : 2)) void conv3x3s1_wave_kernel(ConvArgs a) {
     constexpr int NT = 4, LH = 6, LW = 18, MAXP = 7;
     constexpr int BUFSZ = LH * LW * CP;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256, (BSUM && MT >= 7) ? 1 : (NBUF == 1 ? 3 : 2)) v
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const int n = blockIdx.y;
-    const int mtile0 = blockIdx.z * MT;
+    const int mtile0 = MOFF >= 0 ? blockIdx.z * a.mtp + MOFF : blockIdx.z * MT;
     const int mb = mtile0 / a.mtp, mtin = mtile0 - mb * a.mtp;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = a.oy_base + ty * 8 + (wave >> 1) * 4, ox0 = tx * 32 + (wave & 1) * 16;
@@ -1546,7 +1548,7 @@ void choose_mt(int Cout, int &MT, int &MB) {
 // Tuning knobs: environment variable PMCTF_CONV_<NAME> at first use, or pmctf_conv2d_set_option("<NAME>", v).
 struct Knob { const char *name; long value; bool set; };
 Knob g_knobs[] = {{"WAVE", 1, false}, {"NT", 0, false}, {"MSPLIT_PX", 70000, false}, {"SPLIT", 1, false},
-                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"C16_OCC", 2, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}, {"BIGPX_NOSPLIT", 200000, false}};
+                  {"BIGPX", 131072, false}, {"RES", 0, false}, {"MSPLIT_NT", 1, false}, {"C16", 1, false}, {"C16_WGS", 512, false}, {"C16_OCC", 2, false}, {"V1", 0, false}, {"V2", 0, false}, {"NBUF1", 1, false}, {"K33", 1, false}, {"WAVE_SMALL", 1, false}, {"K11", 1, false}, {"K77", 1, false}, {"K33_SMALL", 1, false}, {"K11_MIN_TILES", 7, false}, {"BIGPX_NOSPLIT", 200000, false}, {"BSUM_SPLIT", 1, false}};
 std::once_flag g_knobs_once;
 inline long knob(const char *name) {
     // one-time, thread-safe read of the environment (ctypes callers may launch from several host threads)
@@ -1634,6 +1636,21 @@ int launch(const ConvArgs &a, int gz, hipStream_t st, int r0, int r1) {
         }
         const bool plain_blocks = sc.bchunks == 1 && !sc.bias_first && a.act <= pm::ACT_LEAKY && a.KH == 3 && a.KW == 3 &&
                                   knob("K33") != 0 && (size_t)a.H * a.W * a.Cin * sizeof(float) < (1ull << 32);
+        if constexpr (NT == 4 && TW16 == 2 && MT == 7) {
+            // 7 cout tiles as 4 + 3 in two launches (both accumulator sets in VGPRs, two workgroups per CU, the chunk sums
+            // folded with packed adds) instead of one launch with the running sums in AGPRs at one workgroup per CU
+            if (plain_blocks && a.S == 1 && wave_eligible(a) && knob("BSUM_SPLIT") != 0 && a.mtp == 7) {
+                const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
+                const size_t wsmem = (size_t)PH * PW * CP * sizeof(float) * 2 * WAVES;
+                static std::once_flag once_k4, once_k3;
+                allow_big_lds(conv3x3s1_wave_kernel<4, 2, true, 0>, once_k4);
+                allow_big_lds(conv3x3s1_wave_kernel<3, 2, true, 4>, once_k3);
+                CONV_LAUNCH((conv3x3s1_wave_kernel<4, 2, true, 0>), grid, dim3(256), wsmem, st, b);
+                { const int rc = pm_launch_status(); if (rc != PMCTF_OK) return rc; }
+                CONV_LAUNCH((conv3x3s1_wave_kernel<3, 2, true, 4>), grid, dim3(256), wsmem, st, b);
+                return pm_launch_status();
+            }
+        }
         if constexpr (NT == 4 && TW16 == 2 && (MT == 1 || MT == 2 || MT == 4 || MT == 7)) {
             if (plain_blocks && a.S == 1 && wave_eligible(a)) {
                 const int PH = 3 * a.S + a.KH, PW = 15 * a.S + a.KW;
