@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "pm_device_math.h"
 #include "launch.h"
 #include "../../include/pmctf_hip.h"
@@ -55,6 +56,8 @@ struct LLArgs {
     int head_b[3];                // 16-channel chunk cb; head_b = B (0: one chain)
 };
 
+__host__ __device__ inline long ll_scratch_acts_dev(int N, int H, int W) { return (long)5 * N * (H + 1) * (W + 2) * NF; }
+
 // reduce-B over 128 input channels: which 16-channel chunks start a new block
 inline unsigned reduce_mask(int B) {
     unsigned m = 0;
@@ -84,7 +87,17 @@ constexpr int GROUPS_TOTAL = 5 * GROUPS_B + 2 * GROUPS_DP; // 880
 constexpr long S_W = W_V1_TOTAL;                          // [GROUPS_TOTAL][NF][4]
 constexpr long S_BIAS = S_W + (long)GROUPS_TOTAL * NF * 4;   // [7][NF]: five type-B layers, two dense layers
 constexpr long S_P2 = S_BIAS + 7 * NF;                    // convs.2 as [2][NF] + bias[2]
-constexpr long W_TOTAL = S_P2 + 2 * NF + 2;
+constexpr long W_TOTAL_V2 = S_P2 + 2 * NF + 2;
+// ---- third layout (the row-wise decode under rule "blocks", ll_ar_row_kernel / ll_ar_pre_kernel): a 16-channel chunk's
+// chain runs over the taps (0,0) (0,1) (0,2) of the row above first, then (1,0) (1,1).  The first 48 terms depend on row
+// h-1 only and are evaluated for a whole row at once (U_W: [layer][chunk][tap < 3][ci][co]); the sequential kernel streams
+// the remaining 32 terms per chunk (R_W: [group][co][4] over k2 = 32 * chunk + 16 * (tap - 3) + ci, then the two dense
+// layers as in the second layout).
+constexpr int GROUPS_R = 8 * 2 * 16 / 4;                  // 64 groups per type-B layer
+constexpr int GROUPS_RTOTAL = 5 * GROUPS_R + 2 * GROUPS_DP;  // 400
+constexpr long R_W = W_TOTAL_V2;                          // [GROUPS_RTOTAL][NF][4]
+constexpr long U_W = R_W + (long)GROUPS_RTOTAL * NF * 4;  // [5][8][3][16][NF]
+constexpr long W_TOTAL = U_W + (long)5 * 8 * 3 * 16 * NF;
 
 __device__ __forceinline__ float leaky02(float v) { return v > 0.0f ? v : v * 0.2f; }
 
@@ -592,6 +605,338 @@ __global__ __launch_bounds__(NF) void ll_ar_stream_kernel(LLArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-wise form of the sequential LL decode under rule "blocks".  A type-B layer's output at (h, w) is, per 16-channel
+// chunk, ONE chain from zero over the taps (h-1, w-1) (h-1, w) (h-1, w+1) (h, w-1) (h, w); the chunk sums are added in
+// turn.  The first 48 terms of every chunk's chain depend on row h-1 only: ll_ar_pre_kernel evaluates them for a whole
+// row at once (all CUs, 8 positions per workgroup so that a weight is fetched once per 8 chains), the sequential kernel
+// continues each chain from that prefix with the 32 terms of the two taps of row h — the same fmaf sequence, the same
+// bits, 2.25x fewer weights to stream per position (0.79 instead of 1.7 MB) and chains of 256 instead of 640 terms.
+// One launch pair per row; the coder state travels in state_out.
+template <int NP>
+__global__ __launch_bounds__(NF) void ll_ar_pre_kernel(LLArgs a, int h) {
+    __shared__ float act[10][NF];
+    const int tid = threadIdx.x;
+    const int l = blockIdx.y / NP, p = blockIdx.y % NP, w0 = blockIdx.x * 8;
+    const int W = a.W;
+    const long plane_sz = (long)a.H * W * NF;
+    const float *src = a.bufs + ((long)l * NP + p) * plane_sz + (long)(h - 1) * W * NF;
+    for (int i = tid; i < 10 * NF; i += NF) {
+        const int col = w0 - 1 + i / NF;
+        act[i / NF][i % NF] = (col >= 0 && col < W) ? src[(long)col * NF + (i % NF)] : 0.0f;
+    }
+    __syncthreads();
+    const float *wu = a.w + U_W + (long)l * 8 * 3 * 16 * NF + tid;
+    float *P = a.bufs + ll_scratch_acts_dev(a.N, a.H, W) + (((long)l * NP + p) * W) * 8 * NF + tid;
+#pragma unroll 1
+    for (int cb = 0; cb < 8; ++cb) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+                const float wv = wu[(long)((cb * 3 + t) * 16 + ci) * NF];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(act[j + t][cb * 16 + ci], wv, acc[j]);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w0 + j < W) P[((long)(w0 + j) * 8 + cb) * NF] = acc[j];
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(NF) void ll_ar_row_kernel(LLArgs a, int h) {
+    constexpr int BLK = 4;                                // float4 groups per ring block; 40 groups (80 KB) in flight
+    constexpr int RING = 10;
+    constexpr int BLOCKS_R = GROUPS_R / BLK;              // 8 or 16 blocks per type-B layer
+    constexpr int BLOCKS_D = GROUPS_DP / BLK;             // 5 or 10 (the last fifth is padding that is never read)
+    constexpr int BLOCKS_TOTAL = 5 * BLOCKS_R + 2 * BLOCKS_D;   // 50 or 100 per position
+    static_assert(BLOCKS_TOTAL % RING == 0, "a position must start at ring slot 0");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;                          // = output channel
+    const int W = a.W, H = a.H;
+    int32_t *l_cdf = (int32_t *)smem;                     // [256][cols]
+    int32_t *l_sizes = l_cdf + 256 * a.cols;
+    int32_t *l_offs = l_sizes + 256;
+    float *l_act = (float *)(l_offs + 256);               // [2][NP][2 * NF]: taps (h, w-1) and (h, w) of the layer's input
+    float *l_left = l_act + 2 * NP * 2 * NF;              // [5][NP][NF]   layer input at (h, w-1)
+    float *l_bias = l_left + 5 * NP * NF;                 // [7][NF]
+    float *l_p2 = l_bias + 7 * NF;                        // [2][NF] + 2
+    float *l_prm = l_p2 + 2 * NF + 2;                     // [NP][2]
+    float *l_rows = l_prm + 2 * NP;                       // [NP][2][W + 2]: decoded values of rows h-1 / h, zero-padded
+    for (int i = tid; i < 256 * a.cols; i += NF) l_cdf[i] = a.cdf[i];
+    for (int i = tid; i < 256; i += NF) { l_sizes[i] = a.sizes[i]; l_offs[i] = a.offsets[i]; }
+    for (int i = tid; i < NP * 2 * (W + 2); i += NF) {
+        const int p = i / (2 * (W + 2)), r = (i / (W + 2)) & 1, c = i % (W + 2);
+        l_rows[i] = (r == 0 && h > 0 && c >= 1 && c <= W) ? a.ll_out[(long)p * H * W + (long)(h - 1) * W + c - 1] : 0.0f;
+    }
+    for (int i = tid; i < 2 * NF + 2; i += NF) l_p2[i] = a.w[S_P2 + i];
+    for (int i = tid; i < 7 * NF; i += NF) l_bias[i] = a.w[S_BIAS + i];
+    for (int i = tid; i < 5 * NP * NF; i += NF) l_left[i] = 0.0f;
+    const float *w = a.w;
+    const float w00 = w[W_L0 + 0 * NF + tid], w01 = w[W_L0 + 1 * NF + tid], w02 = w[W_L0 + 2 * NF + tid],
+                w10 = w[W_L0 + 3 * NF + tid], b0 = w[B_L0 + tid];
+    const f32x4 *ws = (const f32x4 *)(w + R_W) + tid;     // group g of this channel: ws[g * NF]
+    const long plane_sz = (long)H * W * NF;               // scratch: [5 layers][NP][H][W][NF]
+    float *scr = a.bufs + tid;
+    const float *pre = a.bufs + ll_scratch_acts_dev(a.N, H, W) + tid;      // [5][NP][W][8][NF]
+    f32x4 ring[RING][BLK];
+    int nb = 0;                                           // next block of the stream to request
+    auto request = [&](int slot) {                        // slot is a compile-time constant at every use
+        // nb is the same constant at a given site for every position; hidden from the optimiser, which otherwise keeps one
+        // precomputed 64-bit address per site (100 sites: 200 registers, spilled)
+        asm volatile("" : "+s"(nb));
+        const f32x4 *src = ws + (long)nb * BLK * NF;
+#pragma unroll
+        for (int g = 0; g < BLK; ++g) ring[slot][g] = src[(long)g * NF];
+        nb = nb + 1 == BLOCKS_TOTAL ? 0 : nb + 1;
+    };
+#pragma unroll
+    for (int b = 0; b < RING - 1; ++b) request(b);
+    unsigned long long x = h == 0 ? a.x0 : a.state_out[0];
+    long pos = h == 0 ? a.pos0 : (long)a.state_out[1];
+    int err = h == 0 ? 0 : (int)a.state_out[2];
+    // the next word of the stream is fetched when its predecessor is consumed, a position or more before it is needed
+    uint32_t nw = pos < a.n_words ? a.stream[pos] : 0u;
+    const float *row_prev = l_rows, *row_cur_c = l_rows + (W + 2);
+    float *row_cur = l_rows + (W + 2);
+    (void)row_cur_c;
+    // chunk prefixes of (layer 0, position 0)
+    float pn[NP][8];
+    auto fetch_prefix = [&](int layer, int wq) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb)
+                pn[p][cb] = h > 0 ? pre[((((long)layer * NP + p) * W + wq) * 8 + cb) * NF] : 0.0f;
+    };
+    fetch_prefix(0, 0);
+    __syncthreads();
+
+    for (int wq = 0; wq < W; ++wq) {
+        // ---- maskedConv1 (type A, 1 -> 128) on the decoded values: one input channel = one block, bias last
+        float conv1[NP], xin[NP], xres[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float *rp = row_prev + p * 2 * (W + 2) + wq, *rc = row_cur + p * 2 * (W + 2) + wq;
+            float t = 0.0f;                               // padded rows: column wq-1 is at index wq
+            t = __builtin_fmaf(rp[0], w00, t);
+            t = __builtin_fmaf(rp[1], w01, t);
+            t = __builtin_fmaf(rp[2], w02, t);
+            t = __builtin_fmaf(rc[0], w10, t);
+            t = t + b0;
+            conv1[p] = t;
+            xin[p] = t;
+            xres[p] = 0.0f;
+        }
+        const long spos = ((long)h * W + wq) * NF;
+        // ---- five type-B layers (the layer index is a compile-time constant: ring slots are registers)
+        auto type_b = [&](auto layer_c) {
+            constexpr int layer = decltype(layer_c)::value;
+            float *A = l_act + (layer & 1) * NP * 2 * NF;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                scr[((long)layer * NP + p) * plane_sz + spos] = xin[p];
+                float *lf = l_left + (layer * NP + p) * NF + tid;
+                A[p * 2 * NF + tid] = lf[0];
+                A[p * 2 * NF + NF + tid] = xin[p];
+                lf[0] = xin[p];
+            }
+            __syncthreads();
+            float pc[NP][8];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) pc[p][cb] = pn[p][cb];
+            // the next layer's (or the next position's first layer's) prefixes: requested now, needed a layer later
+            if (layer < 4) fetch_prefix(layer + 1, wq);
+            else if (wq + 1 < W) fetch_prefix(0, wq + 1);
+            const float lbias = l_bias[layer * NF + tid];
+            float acc[NP], tot[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { acc[p] = 0.0f; tot[p] = 0.0f; }
+#pragma unroll
+            for (int blk = 0; blk < BLOCKS_R; ++blk) {
+                request((layer * BLOCKS_R + blk + RING - 1) % RING);
+#pragma unroll
+                for (int g = 0; g < BLK; ++g) {
+                    const int k0 = (blk * BLK + g) * 4;               // chain index among the 256 terms of rows h
+                    const int cb = k0 / 32, t = (k0 % 32) / 16, ci = k0 % 16;
+                    if (k0 % 32 == 0) {                                // a chunk starts: its chain continues the prefix
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            if (cb == 1) tot[p] = acc[p] + lbias;
+                            else if (cb > 1) tot[p] = tot[p] + acc[p];
+                            acc[p] = pc[p][cb];
+                        }
+                    }
+                    const f32x4 wv = ring[(layer * BLOCKS_R + blk) % RING][g];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const f32x4 av = *(const f32x4 *)(A + p * 2 * NF + t * NF + cb * 16 + ci);
+                        acc[p] = __builtin_fmaf(av[0], wv[0], acc[p]);
+                        acc[p] = __builtin_fmaf(av[1], wv[1], acc[p]);
+                        acc[p] = __builtin_fmaf(av[2], wv[2], acc[p]);
+                        acc[p] = __builtin_fmaf(av[3], wv[3], acc[p]);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(acc[p]));
+                __builtin_amdgcn_sched_barrier(0);     // keep a block's LDS reads with the block (hoisted, they spill)
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float o = tot[p] + acc[p];
+                if (layer == 0 || layer == 2) { xres[p] = xin[p]; xin[p] = leaky02(o); }
+                else if (layer == 1) xin[p] = o + xres[p];
+                else if (layer == 3) xin[p] = (o + xres[p]) + conv1[p];
+                else xin[p] = leaky02(o);
+            }
+        };
+        type_b(std::integral_constant<int, 0>{});
+        type_b(std::integral_constant<int, 1>{});
+        type_b(std::integral_constant<int, 2>{});
+        type_b(std::integral_constant<int, 3>{});
+        type_b(std::integral_constant<int, 4>{});
+        // ---- head: 128 -> 128 -> 128 -> 2
+        auto dense = [&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            float *A = l_act + ((5 + d) & 1) * NP * 2 * NF;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) A[p * 2 * NF + tid] = xin[p];
+            __syncthreads();
+            float acc[NP], tot[NP];
+            const unsigned hmask = a.head_mask[d];
+            const int hb = a.head_b[d];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { acc[p] = l_bias[(5 + d) * NF + tid]; tot[p] = 0.0f; }
+#pragma unroll
+            for (int blk = 0; blk < BLOCKS_D; ++blk) {
+                request((5 * BLOCKS_R + d * BLOCKS_D + blk + RING - 1) % RING);
+                if (blk < GROUPS_D / BLK) {               // the fifth block is padding that keeps the ring aligned
+#pragma unroll
+                    for (int g = 0; g < BLK; ++g) {
+                        const int k = (blk * BLK + g) * 4;
+                        if (k % 16 == 0 && ((hmask >> (k / 16)) & 1u)) {      // "reduce-B": a block of the reduction ends
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {
+                                tot[p] = k == hb ? acc[p] : tot[p] + acc[p];
+                                acc[p] = 0.0f;
+                            }
+                        }
+                        const f32x4 wv = ring[(5 * BLOCKS_R + d * BLOCKS_D + blk) % RING][g];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const f32x4 av = *(const f32x4 *)(A + p * 2 * NF + k);
+                            acc[p] = __builtin_fmaf(av[0], wv[0], acc[p]);
+                            acc[p] = __builtin_fmaf(av[1], wv[1], acc[p]);
+                            acc[p] = __builtin_fmaf(av[2], wv[2], acc[p]);
+                            acc[p] = __builtin_fmaf(av[3], wv[3], acc[p]);
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(acc[p]));
+                __builtin_amdgcn_sched_barrier(0);     // keep a block's LDS reads with the block (hoisted, they spill)
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) xin[p] = leaky02(hmask ? tot[p] + acc[p] : acc[p]);
+        };
+        dense(std::integral_constant<int, 0>{});
+        dense(std::integral_constant<int, 1>{});
+        {
+            float *A = l_act + (7 & 1) * NP * 2 * NF;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) A[p * 2 * NF + tid] = xin[p];
+            __syncthreads();
+            if (tid < 2 * NP) {                           // (plane, output) pairs: scale and mean of every plane
+                const int p = tid >> 1, o = tid & 1;
+                float acc = l_p2[2 * NF + o], tot = 0.0f;
+                const float *wv = l_p2 + o * NF, *av = A + p * 2 * NF;
+                const unsigned hmask = a.head_mask[2];
+#pragma unroll 1
+                for (int cb = 0; cb < NF / 16; ++cb) {
+                    if ((hmask >> cb) & 1u) {
+                        tot = cb * 16 == a.head_b[2] ? acc : tot + acc;
+                        acc = 0.0f;
+                    }
+#pragma unroll
+                    for (int k = cb * 16; k < cb * 16 + 16; ++k) acc = __builtin_fmaf(av[k], wv[k], acc);
+                }
+                l_prm[p * 2 + o] = hmask ? tot + acc : acc;
+            }
+            __syncthreads();
+        }
+        // ---- entropy decode (wave 0, uniform): plane after plane (pWave.py:566-575)
+        if (tid < 64) {
+#pragma unroll 1
+            for (int pl = 0; pl < NP; ++pl) {
+                float s = l_prm[pl * 2 + 0];
+                const float mean = l_prm[pl * 2 + 1];
+                s = s < 1e-5f ? 1e-5f : s;
+                float iv = (pm::logf_(s) - a.lmin) / a.lstep;
+                iv = iv >= 0.0f ? iv : 0.0f;              // also maps NaN (corrupt stream) to row 0
+                iv = iv > 255.0f ? 255.0f : iv;
+                const int row = (int)iv;
+                const int32_t *cd = l_cdf + row * a.cols;
+                const int size = l_sizes[row];
+                const int max_value = size - 2;
+                const unsigned cum = (unsigned)(x & 0xFFFFull);
+                int cnt = 0;
+                for (int base = 0; base < size; base += 64) {
+                    const int i = base + tid;
+                    const bool le = i < size && (unsigned)cd[i] <= cum;
+                    cnt += __builtin_popcountll(__ballot(le));
+                }
+                const int sidx = cnt - 1;
+                const unsigned start = (unsigned)cd[sidx], freq = (unsigned)(cd[sidx + 1] - cd[sidx]);
+                x = (unsigned long long)freq * (x >> 16) + (x & 0xFFFFull) - start;
+                if (x < (1ull << 31)) {
+                    if (pos < a.n_words) x = (x << 32) | nw; else err = 1;
+                    ++pos;
+                    nw = pos < a.n_words ? a.stream[pos] : 0u;
+                }
+                int value = sidx;
+                if (value == max_value) {                   // bypass digits (rans.cpp:303-325)
+                    auto bits4 = [&]() -> int {
+                        const int val = (int)(x & 15ull);
+                        x >>= 4;
+                        if (x < (1ull << 31)) {
+                            if (pos < a.n_words) x = (x << 32) | nw; else err = 1;
+                            ++pos;
+                            nw = pos < a.n_words ? a.stream[pos] : 0u;
+                        }
+                        return val;
+                    };
+                    int val = bits4();
+                    int n_bypass = val;
+                    while (val == 15) { val = bits4(); n_bypass += val; }
+                    int raw = 0;
+                    for (int j = 0; j < n_bypass; ++j) raw |= bits4() << (j * 4);
+                    value = raw >> 1;
+                    if (raw & 1) value = -value - 1; else value += max_value;
+                }
+                const float q = (float)(short)(value + l_offs[row]);
+                if (tid == 0) {
+                    const float v = __builtin_rintf(q + mean);
+                    row_cur[pl * 2 * (W + 2) + wq + 1] = v;
+                    a.ll_out[(long)pl * H * W + (long)h * W + wq] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.state_out[0] = x;
+        a.state_out[1] = (unsigned long long)pos;
+        a.state_out[2] = (unsigned long long)err;
+    }
+}
+
 // four-step decompress: CDF rows of step k (0 off the mask), then x_hat at the mask positions
 __device__ __forceinline__ int scale_index(float s, float lmin, float step) {
     s = s < 1e-5f ? 1e-5f : s;
@@ -739,10 +1084,37 @@ extern "C" int pmctf_ll_ar_pack_weights(const float *w_a, const float *b_a, cons
         for (int k = 0; k < NF; ++k) out[S_P2 + o * NF + k] = w_p2[(long)o * NF + k];
     out[S_P2 + 2 * NF + 0] = b_p2[0];
     out[S_P2 + 2 * NF + 1] = b_p2[1];
+    // the row-wise layouts
+    long r0 = 0;
+    for (int l = 0; l < 5; ++l) {
+        for (int cb = 0; cb < 8; ++cb)
+            for (int t = 0; t < TB; ++t)
+                for (int ci = 0; ci < 16; ++ci)
+                    for (int co = 0; co < NF; ++co) {
+                        const float v = w_b[l][((long)co * NF + cb * 16 + ci) * 9 + TBT[t][0] * 3 + TBT[t][1]];
+                        if (t < 3) {
+                            out[U_W + ((((long)l * 8 + cb) * 3 + t) * 16 + ci) * NF + co] = v;
+                        } else {
+                            const int k2 = cb * 32 + (t - 3) * 16 + ci;
+                            out[R_W + ((r0 + k2 / 4) * NF + co) * 4 + (k2 & 3)] = v;
+                        }
+                    }
+        r0 += GROUPS_R;
+    }
+    for (int l = 0; l < 2; ++l) {
+        for (int k = 0; k < NF; ++k)
+            for (int co = 0; co < NF; ++co) out[R_W + ((r0 + k / 4) * NF + co) * 4 + (k & 3)] = wp[l][(long)co * NF + k];
+        for (long i = (r0 + GROUPS_D) * NF * 4; i < (r0 + GROUPS_DP) * NF * 4; ++i) out[R_W + i] = 0.0f;
+        r0 += GROUPS_DP;
+    }
     return PMCTF_OK;
 }
 
-extern "C" int64_t pmctf_ll_ar_scratch_floats(int N, int H, int W) { return (int64_t)5 * N * (H + 1) * (W + 2) * NF; }
+// [5 layers][N][H+1][W+2][NF] layer inputs (the kernels address it as [5][N][H][W][NF]) + [5][N][W][8][NF] chunk prefixes of a row
+inline int64_t ll_scratch_acts(int N, int H, int W) { return (int64_t)ll_scratch_acts_dev(N, H, W); }
+extern "C" int64_t pmctf_ll_ar_scratch_floats(int N, int H, int W) {
+    return ll_scratch_acts(N, H, W) + (int64_t)5 * N * W * 8 * NF;
+}
 
 extern "C" int pmctf_ll_ar_decode_f32(const float *w_packed, const uint32_t *stream_words, int64_t n_words, uint64_t x0,
                                       int64_t pos0, const int32_t *cdf, const int32_t *sizes, const int32_t *offsets,
@@ -779,6 +1151,24 @@ extern "C" int pmctf_ll_ar_decode_rules_f32(const float *w_packed, const uint32_
                         ((size_t)2 * N * TB * NF + 5 * N * NF + 5 * N * 4 * NF + 7 * NF + 2 * NF + 2 + 2 * N +
                          (size_t)N * 2 * (W + 2)) * sizeof(float) + 64;
     static const bool v1 = getenv("PMCTF_LL_AR_V1") != nullptr;      // the first kernel, kept for A/B measurements
+    static const bool v2 = getenv("PMCTF_LL_AR_V2") != nullptr;      // the streaming kernel where the row-wise form applies
+    if (!v1 && !v2 && a.blocks && N <= 2 && smem <= 150 * 1024) {
+        // rule "blocks": the row-wise form — per row the chunk prefixes of the whole row (all CUs), then the sequential kernel
+        static std::once_flag once_r[2];
+        hipStream_t st = (hipStream_t)stream;
+        auto row = [&](auto pre_k, auto row_k, std::once_flag &flag) {
+            std::call_once(flag, [row_k] {
+                (void)hipFuncSetAttribute((const void *)row_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+            for (int h = 0; h < H; ++h) {
+                if (h > 0) PM_LAUNCH(pre_k, dim3((W + 7) / 8, 5 * N), dim3(NF), 0, st, a, h);
+                PM_LAUNCH(row_k, dim3(1), dim3(NF), smem, st, a, h);
+            }
+        };
+        if (N == 1) row(ll_ar_pre_kernel<1>, ll_ar_row_kernel<1>, once_r[0]);
+        else row(ll_ar_pre_kernel<2>, ll_ar_row_kernel<2>, once_r[1]);
+        return launch_ok();
+    }
     if (!v1 && N <= 2 && smem <= 150 * 1024) {       // Y and UV streams; three or four planes (RGB stills) keep the first kernel
         static std::once_flag once[LL_MAX_PLANES];
         auto go = [&](auto kernel, std::once_flag &flag) {

@@ -1183,9 +1183,16 @@ class HipEngine:
 
     def pwave_decompress_many(self, jobs):
         """jobs: [(coder, data, padding, q_index, qp_scale)].  All LL decodes run concurrently on side streams."""
+        return self.pwave_decompress_many_end(self.pwave_decompress_many_begin(jobs))
+
+    def pwave_decompress_many_begin(self, jobs):
+        """Parse the files and start their sequential LL decodes (side streams); the caller may do other work — the
+        motion stream's decode — before pwave_decompress_many_end."""
         while len(self.side_streams) < len(jobs):
             self.side_streams.append(torch.cuda.Stream(device=self.dev))
-        begun = [self.pwave_decompress_begin(*j, stream=self.side_streams[i]) for i, j in enumerate(jobs)]
+        return [self.pwave_decompress_begin(*j, stream=self.side_streams[i]) for i, j in enumerate(jobs)]
+
+    def pwave_decompress_many_end(self, begun):
         if len(begun) == 1:
             return [self.pwave_decompress_end(begun[0])]
         # The files are independent: each is finished by its own host thread on its own stream (the four-step decode

@@ -320,6 +320,10 @@ class pMCTF(nn.Module):
 
     def _decompress_files(self, files, code_lt, psize, q_index, stage_idx):
         """H (and L) files of the given (file_name, ischroma) entries; their sequential LL parts decode concurrently"""
+        return self._decompress_files_end(self._decompress_files_begin(files, code_lt, psize, q_index, stage_idx))
+
+    def _decompress_files_begin(self, files, code_lt, psize, q_index, stage_idx):
+        """read the files and start their sequential LL decodes on side streams (finish with _decompress_files_end)"""
         from pMCTF.hip.engine import get_curr_q
         self.flush()            # the files of deferred pairs must exist before they are read
         eng = self.engine()
@@ -333,7 +337,11 @@ class pMCTF(nn.Module):
                 file_name_l = file_name.replace(osp.basename(file_name), "0_C_main.bin" if ischroma else "0_main.bin")
                 with open(file_name_l, "rb") as f:
                     jobs.append(("lp_coder", f.read(), pad, q_index, None))
-        planes = eng.pwave_decompress_many(jobs)
+        return files, code_lt, eng.pwave_decompress_many_begin(jobs)
+
+    def _decompress_files_end(self, begun):
+        files, code_lt, jobs = begun
+        planes = self.engine().pwave_decompress_many_end(jobs)
         out, i = [], 0
         for _ in files:
             H_t = planes[i]; i += 1
@@ -741,13 +749,15 @@ class pMCTF(nn.Module):
             mv_y_q_index, string = decode_p(mv_out)
             # (the reference passes the full-resolution size and no factor here, pMCTF_L.py:597-602, which cannot
             # decode a reduced-resolution motion stream; the stream is decoded at the size it was coded at)
+            # the pictures' sequential LL parts start first (one CU each, side streams): the motion stream decodes under them
+            begun = self._decompress_files_begin([(output_path, False), (file_name_c, True)], code_lt, psize, q_index,
+                                                 stage_idx)
             decoded = self.decompress_mv(string, ref_y.dtype, ref_y.size(2) // me_downsample,
                                          ref_y.size(3) // me_downsample, dpb, stage_idx=stage_idx, q_index=q_index,
                                          me_downsample=me_downsample)
             mv_hat = decoded["mv_hat"]
             mv_feature = decoded["mv_feature"].permute(0, 2, 3, 1)
-            out_dec, out_dec_c = self._decompress_files([(output_path, False), (file_name_c, True)], code_lt, psize,
-                                                        q_index, stage_idx)
+            out_dec, out_dec_c = self._decompress_files_end(begun)
             torch.cuda.synchronize()
             decoding_time = time.time() - t0
             luma = dict(luma, H_t_hat=out_dec["H_t"]["x_hat"], L_t_hat=out_dec["L_t"]["x_hat"] if code_lt else None)
