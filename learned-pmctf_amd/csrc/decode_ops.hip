@@ -937,6 +937,318 @@ __global__ __launch_bounds__(NF) void ll_ar_row_kernel(LLArgs a, int h) {
     }
 }
 
+
+// The same row kernel on 256 threads: under rule "blocks" the eight chunk sums of an output channel are independent chains,
+// so TWO threads share a channel — chunks 0-3 and 4-7 — each streaming half of the layer's weights through its own register
+// ring (twice the bytes in flight, half the chain length, all four SIMDs); the second thread hands its four sums over
+// through LDS and the first adds all eight in order ((S_0 + bias) + S_1 + ... + S_7: the same additions).  The dense
+// head layers are single chains and stay on the first 128 threads.
+template <int NP, int HALF>
+__device__ __forceinline__ void ll_ar_row2_body(const LLArgs &a, const int h, float *smem) {
+    constexpr int BLK = 4, RING = 10;
+    constexpr int BLOCKS_R = GROUPS_R / 2 / BLK;          // 8 blocks per type-B layer and half
+    constexpr int BLOCKS_D = GROUPS_DP / BLK;             // 10 (the last fifth is padding that is never read)
+    constexpr int BLOCKS_TOTAL = 5 * BLOCKS_R + (HALF == 0 ? 2 * BLOCKS_D : 0);   // 60 or 40 per position
+    static_assert(BLOCKS_TOTAL % RING == 0, "a position must start at ring slot 0");
+    const int tid = threadIdx.x & (NF - 1);               // = output channel
+    const int W = a.W, H = a.H;
+    int32_t *l_cdf = (int32_t *)smem;                     // [256][cols]
+    int32_t *l_sizes = l_cdf + 256 * a.cols;
+    int32_t *l_offs = l_sizes + 256;
+    float *l_act = (float *)(l_offs + 256);               // [2][NP][2 * NF]: taps (h, w-1) and (h, w) of the layer's input
+    float *l_left = l_act + 2 * NP * 2 * NF;              // [5][NP][NF]   layer input at (h, w-1)
+    float *l_bias = l_left + 5 * NP * NF;                 // [7][NF]
+    float *l_p2 = l_bias + 7 * NF;                        // [2][NF] + 2
+    float *l_prm = l_p2 + 2 * NF + 2;                     // [NP][2]
+    float *l_s = l_prm + 2 * NP;                          // [NP][4][NF]: chunk sums 4..7 on their way to the first half
+    float *l_rows = l_s + NP * 4 * NF;                    // [NP][2][W + 2]: decoded values of rows h-1 / h, zero-padded
+    {
+        const int t2 = threadIdx.x;
+        for (int i = t2; i < 256 * a.cols; i += 2 * NF) l_cdf[i] = a.cdf[i];
+        for (int i = t2; i < 256; i += 2 * NF) { l_sizes[i] = a.sizes[i]; l_offs[i] = a.offsets[i]; }
+        for (int i = t2; i < NP * 2 * (W + 2); i += 2 * NF) {
+            const int p = i / (2 * (W + 2)), r = (i / (W + 2)) & 1, c = i % (W + 2);
+            l_rows[i] = (r == 0 && h > 0 && c >= 1 && c <= W) ? a.ll_out[(long)p * H * W + (long)(h - 1) * W + c - 1] : 0.0f;
+        }
+        for (int i = t2; i < 2 * NF + 2; i += 2 * NF) l_p2[i] = a.w[S_P2 + i];
+        for (int i = t2; i < 7 * NF; i += 2 * NF) l_bias[i] = a.w[S_BIAS + i];
+        for (int i = t2; i < 5 * NP * NF; i += 2 * NF) l_left[i] = 0.0f;
+    }
+    const float *w = a.w;
+    const float w00 = w[W_L0 + 0 * NF + tid], w01 = w[W_L0 + 1 * NF + tid], w02 = w[W_L0 + 2 * NF + tid],
+                w10 = w[W_L0 + 3 * NF + tid], b0 = w[B_L0 + tid];
+    const f32x4 *ws = (const f32x4 *)(w + R_W) + tid;     // group g of this channel: ws[g * NF]
+    const long plane_sz = (long)H * W * NF;               // scratch: [5 layers][NP][H][W][NF]
+    float *scr = a.bufs + tid;
+    const float *pre = a.bufs + ll_scratch_acts_dev(a.N, H, W) + tid;      // [5][NP][W][8][NF]
+    f32x4 ring[RING][BLK];
+    int nb = 0;                                           // next block of this half's stream to request
+    auto request = [&](int slot) {                        // slot is a compile-time constant at every use
+        asm volatile("" : "+s"(nb));                      // (hidden from the optimiser: see ll_ar_row_kernel)
+        // block nb of this half: layer nb / 8, groups 64 * layer + 32 * HALF + 4 * (nb % 8) ..; then the dense layers
+        const int g0 = nb < 5 * BLOCKS_R ? (nb >> 3) * GROUPS_R + HALF * (GROUPS_R / 2) + (nb & 7) * BLK
+                                         : 5 * GROUPS_R + (nb - 5 * BLOCKS_R) * BLK;
+        const f32x4 *src = ws + (long)g0 * NF;
+#pragma unroll
+        for (int g = 0; g < BLK; ++g) ring[slot][g] = src[(long)g * NF];
+        nb = nb + 1 == BLOCKS_TOTAL ? 0 : nb + 1;
+    };
+#pragma unroll
+    for (int b = 0; b < RING - 1; ++b) request(b);
+    unsigned long long x = h == 0 ? a.x0 : a.state_out[0];
+    long pos = h == 0 ? a.pos0 : (long)a.state_out[1];
+    int err = h == 0 ? 0 : (int)a.state_out[2];
+    uint32_t nw = pos < a.n_words ? a.stream[pos] : 0u;
+    const float *row_prev = l_rows;
+    float *row_cur = l_rows + (W + 2);
+    float pn[NP][4];                                      // chunk prefixes of this half's chunks
+    auto fetch_prefix = [&](int layer, int wq) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                pn[p][c] = h > 0 ? pre[((((long)layer * NP + p) * W + wq) * 8 + 4 * HALF + c) * NF] : 0.0f;
+    };
+    fetch_prefix(0, 0);
+    __syncthreads();
+
+    for (int wq = 0; wq < W; ++wq) {
+        float conv1[NP], xin[NP], xres[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float *rp = row_prev + p * 2 * (W + 2) + wq, *rc = row_cur + p * 2 * (W + 2) + wq;
+            float t = 0.0f;                               // padded rows: column wq-1 is at index wq
+            t = __builtin_fmaf(rp[0], w00, t);
+            t = __builtin_fmaf(rp[1], w01, t);
+            t = __builtin_fmaf(rp[2], w02, t);
+            t = __builtin_fmaf(rc[0], w10, t);
+            t = t + b0;
+            conv1[p] = t;
+            xin[p] = t;
+            xres[p] = 0.0f;
+        }
+        const long spos = ((long)h * W + wq) * NF;
+        auto type_b = [&](auto layer_c) {
+            constexpr int layer = decltype(layer_c)::value;
+            float *A = l_act + (layer & 1) * NP * 2 * NF;
+            if constexpr (HALF == 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    scr[((long)layer * NP + p) * plane_sz + spos] = xin[p];
+                    float *lf = l_left + (layer * NP + p) * NF + tid;
+                    A[p * 2 * NF + tid] = lf[0];
+                    A[p * 2 * NF + NF + tid] = xin[p];
+                    lf[0] = xin[p];
+                }
+            }
+            __syncthreads();
+            float S[NP][4];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) S[p][c] = pn[p][c];
+            if (layer < 4) fetch_prefix(layer + 1, wq);
+            else if (wq + 1 < W) fetch_prefix(0, wq + 1);
+#pragma unroll
+            for (int blk = 0; blk < BLOCKS_R; ++blk) {
+                request((layer * BLOCKS_R + blk + RING - 1) % RING);
+#pragma unroll
+                for (int g = 0; g < BLK; ++g) {
+                    const int k0 = (blk * BLK + g) * 4;               // chain index among this half's 128 terms of row h
+                    const int c = k0 / 32, t = (k0 % 32) / 16, ci = k0 % 16;
+                    const f32x4 wv = ring[(layer * BLOCKS_R + blk) % RING][g];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const f32x4 av = *(const f32x4 *)(A + p * 2 * NF + t * NF + (4 * HALF + c) * 16 + ci);
+                        S[p][c] = __builtin_fmaf(av[0], wv[0], S[p][c]);
+                        S[p][c] = __builtin_fmaf(av[1], wv[1], S[p][c]);
+                        S[p][c] = __builtin_fmaf(av[2], wv[2], S[p][c]);
+                        S[p][c] = __builtin_fmaf(av[3], wv[3], S[p][c]);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(S[p][c]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (HALF == 1) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l_s[(p * 4 + c) * NF + tid] = S[p][c];
+            }
+            __syncthreads();
+            if constexpr (HALF == 0) {
+                const float lbias = l_bias[layer * NF + tid];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    float o = S[p][0] + lbias;
+                    o = o + S[p][1];
+                    o = o + S[p][2];
+                    o = o + S[p][3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o = o + l_s[(p * 4 + c) * NF + tid];
+                    if (layer == 0 || layer == 2) { xres[p] = xin[p]; xin[p] = leaky02(o); }
+                    else if (layer == 1) xin[p] = o + xres[p];
+                    else if (layer == 3) xin[p] = (o + xres[p]) + conv1[p];
+                    else xin[p] = leaky02(o);
+                }
+            }
+        };
+        type_b(std::integral_constant<int, 0>{});
+        type_b(std::integral_constant<int, 1>{});
+        type_b(std::integral_constant<int, 2>{});
+        type_b(std::integral_constant<int, 3>{});
+        type_b(std::integral_constant<int, 4>{});
+        // ---- head: 128 -> 128 -> 128 -> 2 (single chains: the first half; the second half keeps the barriers)
+        auto dense = [&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            float *A = l_act + ((5 + d) & 1) * NP * 2 * NF;
+            if constexpr (HALF == 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) A[p * 2 * NF + tid] = xin[p];
+            }
+            __syncthreads();
+            if constexpr (HALF == 0) {
+                float acc[NP], tot[NP];
+                const unsigned hmask = a.head_mask[d];
+                const int hb = a.head_b[d];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { acc[p] = l_bias[(5 + d) * NF + tid]; tot[p] = 0.0f; }
+#pragma unroll
+                for (int blk = 0; blk < BLOCKS_D; ++blk) {
+                    request((5 * BLOCKS_R + d * BLOCKS_D + blk + RING - 1) % RING);
+                    if (blk < GROUPS_D / BLK) {           // the fifth block is padding that keeps the ring aligned
+#pragma unroll
+                        for (int g = 0; g < BLK; ++g) {
+                            const int k = (blk * BLK + g) * 4;
+                            if (k % 16 == 0 && ((hmask >> (k / 16)) & 1u)) {      // "reduce-B": a block of the reduction ends
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) {
+                                    tot[p] = k == hb ? acc[p] : tot[p] + acc[p];
+                                    acc[p] = 0.0f;
+                                }
+                            }
+                            const f32x4 wv = ring[(5 * BLOCKS_R + d * BLOCKS_D + blk) % RING][g];
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {
+                                const f32x4 av = *(const f32x4 *)(A + p * 2 * NF + k);
+                                acc[p] = __builtin_fmaf(av[0], wv[0], acc[p]);
+                                acc[p] = __builtin_fmaf(av[1], wv[1], acc[p]);
+                                acc[p] = __builtin_fmaf(av[2], wv[2], acc[p]);
+                                acc[p] = __builtin_fmaf(av[3], wv[3], acc[p]);
+                            }
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(acc[p]));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xin[p] = leaky02(hmask ? tot[p] + acc[p] : acc[p]);
+            }
+        };
+        dense(std::integral_constant<int, 0>{});
+        dense(std::integral_constant<int, 1>{});
+        {
+            float *A = l_act + (7 & 1) * NP * 2 * NF;
+            if constexpr (HALF == 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) A[p * 2 * NF + tid] = xin[p];
+            }
+            __syncthreads();
+            if (HALF == 0 && tid < 2 * NP) {              // (plane, output) pairs: scale and mean of every plane
+                const int p = tid >> 1, o = tid & 1;
+                float acc = l_p2[2 * NF + o], tot = 0.0f;
+                const float *wv = l_p2 + o * NF, *av = A + p * 2 * NF;
+                const unsigned hmask = a.head_mask[2];
+#pragma unroll 1
+                for (int cb = 0; cb < NF / 16; ++cb) {
+                    if ((hmask >> cb) & 1u) {
+                        tot = cb * 16 == a.head_b[2] ? acc : tot + acc;
+                        acc = 0.0f;
+                    }
+#pragma unroll
+                    for (int k = cb * 16; k < cb * 16 + 16; ++k) acc = __builtin_fmaf(av[k], wv[k], acc);
+                }
+                l_prm[p * 2 + o] = hmask ? tot + acc : acc;
+            }
+            __syncthreads();
+        }
+        // ---- entropy decode (wave 0 = the first 64 threads of the first half, uniform): plane after plane
+        if (HALF == 0 && tid < 64) {
+#pragma unroll 1
+            for (int pl = 0; pl < NP; ++pl) {
+                float s = l_prm[pl * 2 + 0];
+                const float mean = l_prm[pl * 2 + 1];
+                s = s < 1e-5f ? 1e-5f : s;
+                float iv = (pm::logf_(s) - a.lmin) / a.lstep;
+                iv = iv >= 0.0f ? iv : 0.0f;              // also maps NaN (corrupt stream) to row 0
+                iv = iv > 255.0f ? 255.0f : iv;
+                const int row = (int)iv;
+                const int32_t *cd = l_cdf + row * a.cols;
+                const int size = l_sizes[row];
+                const int max_value = size - 2;
+                const unsigned cum = (unsigned)(x & 0xFFFFull);
+                int cnt = 0;
+                for (int base = 0; base < size; base += 64) {
+                    const int i = base + tid;
+                    const bool le = i < size && (unsigned)cd[i] <= cum;
+                    cnt += __builtin_popcountll(__ballot(le));
+                }
+                const int sidx = cnt - 1;
+                const unsigned start = (unsigned)cd[sidx], freq = (unsigned)(cd[sidx + 1] - cd[sidx]);
+                x = (unsigned long long)freq * (x >> 16) + (x & 0xFFFFull) - start;
+                if (x < (1ull << 31)) {
+                    if (pos < a.n_words) x = (x << 32) | nw; else err = 1;
+                    ++pos;
+                    nw = pos < a.n_words ? a.stream[pos] : 0u;
+                }
+                int value = sidx;
+                if (value == max_value) {                   // bypass digits (rans.cpp:303-325)
+                    auto bits4 = [&]() -> int {
+                        const int val = (int)(x & 15ull);
+                        x >>= 4;
+                        if (x < (1ull << 31)) {
+                            if (pos < a.n_words) x = (x << 32) | nw; else err = 1;
+                            ++pos;
+                            nw = pos < a.n_words ? a.stream[pos] : 0u;
+                        }
+                        return val;
+                    };
+                    int val = bits4();
+                    int n_bypass = val;
+                    while (val == 15) { val = bits4(); n_bypass += val; }
+                    int raw = 0;
+                    for (int j = 0; j < n_bypass; ++j) raw |= bits4() << (j * 4);
+                    value = raw >> 1;
+                    if (raw & 1) value = -value - 1; else value += max_value;
+                }
+                const float q = (float)(short)(value + l_offs[row]);
+                if (tid == 0) {
+                    const float v = __builtin_rintf(q + mean);
+                    row_cur[pl * 2 * (W + 2) + wq + 1] = v;
+                    a.ll_out[(long)pl * H * W + (long)h * W + wq] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (HALF == 0 && tid == 0) {
+        a.state_out[0] = x;
+        a.state_out[1] = (unsigned long long)pos;
+        a.state_out[2] = (unsigned long long)err;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(2 * NF) void ll_ar_row2_kernel(LLArgs a, int h) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (threadIdx.x < NF) ll_ar_row2_body<NP, 0>(a, h, smem);
+    else ll_ar_row2_body<NP, 1>(a, h, smem);
+}
+
 // four-step decompress: CDF rows of step k (0 off the mask), then x_hat at the mask positions
 __device__ __forceinline__ int scale_index(float s, float lmin, float step) {
     s = s < 1e-5f ? 1e-5f : s;
@@ -1154,19 +1466,26 @@ extern "C" int pmctf_ll_ar_decode_rules_f32(const float *w_packed, const uint32_
     static const bool v2 = getenv("PMCTF_LL_AR_V2") != nullptr;      // the streaming kernel where the row-wise form applies
     if (!v1 && !v2 && a.blocks && N <= 2 && smem <= 150 * 1024) {
         // rule "blocks": the row-wise form — per row the chunk prefixes of the whole row (all CUs), then the sequential kernel
-        static std::once_flag once_r[2];
+        static std::once_flag once_r[4];
+        static const bool one_thread = getenv("PMCTF_LL_AR_ROW1") != nullptr;    // one thread per channel (A/B measurements)
         hipStream_t st = (hipStream_t)stream;
-        auto row = [&](auto pre_k, auto row_k, std::once_flag &flag) {
+        auto row = [&](auto pre_k, auto row_k, std::once_flag &flag, int threads, size_t lds) {
             std::call_once(flag, [row_k] {
                 (void)hipFuncSetAttribute((const void *)row_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             });
             for (int h = 0; h < H; ++h) {
                 if (h > 0) PM_LAUNCH(pre_k, dim3((W + 7) / 8, 5 * N), dim3(NF), 0, st, a, h);
-                PM_LAUNCH(row_k, dim3(1), dim3(NF), smem, st, a, h);
+                PM_LAUNCH(row_k, dim3(1), dim3(threads), lds, st, a, h);
             }
         };
-        if (N == 1) row(ll_ar_pre_kernel<1>, ll_ar_row_kernel<1>, once_r[0]);
-        else row(ll_ar_pre_kernel<2>, ll_ar_row_kernel<2>, once_r[1]);
+        const size_t smem2 = smem + (size_t)N * 4 * NF * sizeof(float);
+        if (one_thread || smem2 > 150 * 1024) {
+            if (N == 1) row(ll_ar_pre_kernel<1>, ll_ar_row_kernel<1>, once_r[0], NF, smem);
+            else row(ll_ar_pre_kernel<2>, ll_ar_row_kernel<2>, once_r[1], NF, smem);
+        } else {
+            if (N == 1) row(ll_ar_pre_kernel<1>, ll_ar_row2_kernel<1>, once_r[2], 2 * NF, smem2);
+            else row(ll_ar_pre_kernel<2>, ll_ar_row2_kernel<2>, once_r[3], 2 * NF, smem2);
+        }
         return launch_ok();
     }
     if (!v1 && N <= 2 && smem <= 150 * 1024) {       // Y and UV streams; three or four planes (RGB stills) keep the first kernel

@@ -382,32 +382,48 @@ int pmctf_rans_decoder_decode_stream(pmctf_rans_decoder *d, const int16_t *index
         auto &p = d->parts[(size_t)pi];
         const int64_t b = pi * each;
         const int64_t cnt = pi < nparts - 1 ? each : n - each * (nparts - 1);
+        // the coder state in locals for the whole run (through `p` every symbol would store and reload it: the int16 /
+        // uint32 accesses of the loop may alias the struct as far as the compiler can tell)
+        uint64_t x = p.x;
+        const uint32_t *ptr = p.ptr;
+        const uint32_t *const end = p.end;
         auto get_bits = [&](uint32_t nbits) -> uint32_t {
-            uint64_t x = p.x;
             const uint32_t val = (uint32_t)(x & ((1u << nbits) - 1));
             x >>= nbits;
-            if (x < kRansL && p.ptr <= p.end) { x = (x << 32) | *p.ptr; p.ptr += 1; }
-            p.x = x;
+            if (x < kRansL && ptr <= end) { x = (x << 32) | *ptr; ptr += 1; }
             return val;
         };
+        int rc = PMCTF_RANS_OK;
         for (int64_t i = b; i < b + cnt; ++i) {
             const int32_t row = indexes[i];
-            if (row < 0 || row >= cdf_rows) return PMCTF_RANS_EINVAL;
+            if (row < 0 || row >= cdf_rows) { rc = PMCTF_RANS_EINVAL; break; }
             const int32_t offset = offsets[row];
             const int32_t *cdf = cdfs + (size_t)row * cdf_cols;
             const int32_t size = cdf_sizes[row];
             const int32_t max_value = size - 2;
-            const uint32_t cum = (uint32_t)(p.x & ((1u << kPrecision) - 1));
-            int32_t s = 0;
-            while (s < size && (uint32_t)cdf[s] <= cum) ++s;
+            const uint32_t cum = (uint32_t)(x & ((1u << kPrecision) - 1));
+            // s = (number of leading entries <= cum) - 1; the rows are non-decreasing: narrow rows by a short scan, wide
+            // rows (large scales: ~100 entries) by bisection
+            int32_t s;
+            if (size <= 8) {
+                s = 0;
+                while (s < size && (uint32_t)cdf[s] <= cum) ++s;
+            } else {
+                int32_t lo = 0, len = size;               // first index in [0, size) whose entry is > cum
+                while (len > 0) {
+                    const int32_t half = len >> 1;
+                    const bool le = (uint32_t)cdf[lo + half] <= cum;
+                    lo = le ? lo + half + 1 : lo;
+                    len = le ? len - half - 1 : half;
+                }
+                s = lo;
+            }
             s -= 1;
-            if (s < 0 || s + 1 >= cdf_cols) return PMCTF_RANS_ESTREAM;
+            if (s < 0 || s + 1 >= cdf_cols) { rc = PMCTF_RANS_ESTREAM; break; }
             {
                 const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
-                uint64_t x = p.x;
                 x = (uint64_t)freq * (x >> kPrecision) + (x & ((1ull << kPrecision) - 1)) - start;
-                if (x < kRansL && p.ptr <= p.end) { x = (x << 32) | *p.ptr; p.ptr += 1; }
-                p.x = x;
+                if (x < kRansL && ptr <= end) { x = (x << 32) | *ptr; ptr += 1; }
             }
             int32_t value = s;
             if (value == max_value) {
@@ -427,6 +443,9 @@ int pmctf_rans_decoder_decode_stream(pmctf_rans_decoder *d, const int16_t *index
             }
             out[i] = (int16_t)(value + offset);
         }
+        p.x = x;
+        p.ptr = const_cast<decltype(p.ptr)>(ptr);
+        if (rc != PMCTF_RANS_OK) return rc;
     }
     return PMCTF_RANS_OK;
 }
