@@ -149,8 +149,9 @@ def main():
                     help="what `value` times.  pairs (default): the reference harness's loop, one encode_one_stage call per "
                          "frame pair, bit counts looked at after every call.  stages: the pairs of each temporal stage as "
                          "one batch (encode_stage_pairs): same files and bits, larger launches.")
-    ap.add_argument("--aux_precisions", default="bf16x3,bf16x2,bf16",
-                    help="auxiliary reduced-precision profiles measured after the exact run ('' to skip)")
+    ap.add_argument("--aux_precisions", default="f32-chain,bf16x3,bf16x2,bf16",
+                    help="auxiliary profiles measured after the exact run ('' to skip): f32-chain (entropy-parameter networks "
+                         "as plain chains: faster, a CDF row off now and then) and the reduced-precision ones")
     ap.add_argument("--cross_gops", type=int, default=4, help="K of the auxiliary cross-GOP stage-batched figure")
     ap.add_argument("--inflight", type=int, default=1,
                     help="closed GOPs coded concurrently on this GPU (one host thread + HIP stream each; a step is then "
@@ -549,7 +550,8 @@ def main():
                     res[name] = {"decoding_time_s": min(ts), "encoding_time_s": r["encoding_time"]}
                 out["decode_pair"] = dict(res, unit="s per 1080p pair (motion + luma + chroma streams, files read back)",
                                           schedule="encode_one_stage(skip_decoding=False): decompress_mv + decompress_one_stage "
-                                                   "of luma and chroma; the sequential LL subband decodes inside one persistent kernel")
+                                                   "of luma and chroma; the sequential LL subband decodes row by row (per row: the row-above part of every chain on "
+                                                   "all CUs, then one sequential workgroup), the motion stream under it")
             optional("decode_pair", decode_pair)
 
         if aux and args.aux_precisions:
@@ -575,8 +577,12 @@ def main():
                 ps_p = pmctf_gop.gop_psnr(pmctf_gop.decode_gop(net, [list(f) for f in e_p["frames_coded"]]), frames, H, W)
                 blk = {"value": args.gop * k_p / t_p, "unit": "frames/s", "ms_per_step": t_p / k_p * 1e3, "steps": k_p,
                        "dtype": {"bf16x3": "bf16 x3 split operands, f32 accumulate", "bf16x2": "bf16 x2 split, f32 accumulate",
-                                 "bf16": "bf16, f32 accumulate"}.get(prec, prec),
-                       "scope": "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px, stride 1 and the stride-2 quarter-resolution context convolutions (conv_split.hip); all else exact f32",
+                                 "bf16": "bf16, f32 accumulate", "f32-chain": "f32"}.get(prec, prec),
+                       "scope": ("f32 everywhere; the entropy-parameter networks (context fusion, LL network, conv-LSTM) sum every "
+                                 "convolution as one chain from the bias instead of ATen's per-block order, torch.sigmoid without "
+                                 "the scalar tails: coefficients and motion as the reference's, CDF rows not always")
+                                if prec == "f32-chain" else
+                                "3x3 convolutions with 64 / 112 couts on planes >= 30 000 px, stride 1 and the stride-2 quarter-resolution context convolutions (conv_split.hip); all else f32 as in f32-chain",
                        "schedule": sched_text[args.schedule],
                        "stage_batched": {"value": args.gop * k_p / t_pb, "ms_per_step": t_pb / k_p * 1e3,
                                          "schedule": sched_text["stages"],
