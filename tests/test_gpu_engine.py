@@ -723,7 +723,8 @@ def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
 
 
 _ATEN_OTHER = [c for c in ((8, 3, "layers", (1920, 1080), 1), (16, 3, "layers", (1920, 1080), 1), (8, 3, "pan", (1366, 768), 1),
-                            (2, 3, "layers", (3840, 2160), 1), (8, 3, "pan", (1920, 1080), 2), (4, 3, "layers", (1280, 720), 1))
+                            (2, 3, "layers", (3840, 2160), 1), (8, 3, "pan", (1920, 1080), 2), (4, 3, "layers", (1280, 720), 1),
+                            (4, 12, "pan", (832, 480), 1), (2, 3, "layers", (2560, 1440), 1))
                if os.path.exists(_digest_path(c[0], c[1], c[2], c[3], c[4]))]
 
 
