@@ -473,3 +473,33 @@ def test_elementwise_ops_every_layout(cuda):
         tc = ta.clone() if ta.is_contiguous() else place(dev(a))
         ops.ew(ops.EW_ADD, tc, tb, out=tc)
         assert_same(tc.cpu().numpy(), a + b, f"ew in place on {name}")
+
+
+@pytest.mark.gpu
+def test_lstm_gates_with_aten_thread_tails(cuda):
+    """lstm_gates (long_context.py:20-33) against the oracle's primitives: sigmoid as ATen evaluates it with 8 intra-op
+    threads on the reference's contiguous (planes, C, H, W) gate tensor — SLEEF on whole strides of 32 floats of a thread's
+    slice, libm's expf on the rest (the (2, 3, 144, 240) tensor of the path: seven slices of 29 623 elements) — and the same
+    values when two reference tensors are stacked into one batch (ref_planes)."""
+    from pmctf_oracle import clib
+    from pMCTF.hip import ops
+    rng = _rng(77)
+    for (n_ref, c, h, w, cc) in ((2, 3, 144, 240, 1), (1, 32, 36, 60, 32), (2, 3, 30, 44, 3)):
+        xs, cells, refs = [], [], []
+        for rep in range(2):
+            x = (rng.standard_normal((n_ref, c, h, w)) * 3).astype(np.float32)
+            cell = rng.standard_normal((n_ref, cc, h, w)).astype(np.float32)
+            g = clib.sigmoid(x, 8)
+            ct = clib.tanh(x)
+            cn = g * cell + g * ct
+            hid = g * clib.tanh(np.ascontiguousarray(cn))
+            xs.append(x); cells.append(cell); refs.append((hid, cn))
+        assert not np.array_equal(clib.sigmoid(xs[0], 8), clib.sigmoid(xs[0])) or (n_ref, c, h, w) != (2, 3, 144, 240)
+        nhwc = lambda t: torch.from_numpy(np.ascontiguousarray(t.transpose(0, 2, 3, 1))).cuda()
+        for rep in range(2):                                   # one reference tensor per call
+            hid, cn = ops.lstm_gates(nhwc(xs[rep]), nhwc(cells[rep]), ref_planes=n_ref, aten_threads=8)
+            assert_same(hid.permute(0, 3, 1, 2).cpu().numpy(), refs[rep][0], "hidden")
+            assert_same(cn.permute(0, 3, 1, 2).cpu().numpy(), refs[rep][1], "cell")
+        hid, cn = ops.lstm_gates(nhwc(np.concatenate(xs)), nhwc(np.concatenate(cells)), ref_planes=n_ref, aten_threads=8)
+        assert_same(hid.permute(0, 3, 1, 2).cpu().numpy(), np.concatenate([r[0] for r in refs]), "hidden, stacked batch")
+        assert_same(cn.permute(0, 3, 1, 2).cpu().numpy(), np.concatenate([r[1] for r in refs]), "cell, stacked batch")
