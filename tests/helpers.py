@@ -12,14 +12,14 @@ def golden(name="reference_128x128.npz"):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def product_model(num_me_stages=1, device="cuda", lazy=False):
+def product_model(num_me_stages=1, device="cuda", lazy=False, weights_seed=0):
     """pMCTF (HIP product) with the deterministic synthetic weights, ready to encode.  lazy=False: encode_one_stage
     returns finished results call by call (what most tests assume: they look at files and tensors right away);
     lazy=True: the product's default, pairs deferred and coded per temporal stage (pMCTF.hip.deferred)."""
     import pmctf_synth
     from pMCTF.models.video.pMCTF_L import pMCTF
     net = pMCTF(num_me_stages=num_me_stages).eval()
-    sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=0)
+    sd = pmctf_synth.synth_state_dict(net.state_dict(), seed=weights_seed)
     net.load_state_dict(sd, strict=True)
     net = net.to(device)
     net.update(force=True)

@@ -511,11 +511,12 @@ def test_gop4_960x544_vs_reference(setup):
     assert same == 11 and diff == 0, (same, diff)
 
 
-def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1):
+def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, weights_seed=0):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_%dx%d_gop%d_me4%s%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
-                                                                        "" if sequence == "pan" else "_" + sequence,
-                                                                        "" if me_downsample == 1 else f"_ds{me_downsample}"))
+                        "reference_%dx%d_gop%d_me4%s%s%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
+                                                                          "" if sequence == "pan" else "_" + sequence,
+                                                                          "" if me_downsample == 1 else f"_ds{me_downsample}",
+                                                                          "" if weights_seed == 0 else f"_w{weights_seed}"))
 
 
 # BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
@@ -530,14 +531,14 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, precision="f32"):
+def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, precision="f32", weights_seed=0):
     import hashlib
     import pmctf_gop
-    key = (gop, q_index, sequence, size, me_downsample, precision)
+    key = (gop, q_index, sequence, size, me_downsample, precision, weights_seed)
     if key in _headline_cache:
         return _headline_cache[key]
-    g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample))
-    net, _ = product_model(4)
+    g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample, weights_seed))
+    net, _ = product_model(4, weights_seed=weights_seed)
     net.precision = precision
     assert net.engine().precision == precision
     net.engine().keep_streams = True
@@ -572,7 +573,7 @@ def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample
            "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
     print(f"{w}x{h} GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
           f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
-    d = os.environ.get("PMCTF_HEADLINE_REPORT") if precision == "f32" else None
+    d = os.environ.get("PMCTF_HEADLINE_REPORT") if precision == "f32" and weights_seed == 0 else None
     if d:       # builder's measuring run: collect what the pins file is written from
         import json
         os.makedirs(d, exist_ok=True)
@@ -739,6 +740,17 @@ def test_every_file_is_the_reference_s_other_sequences_and_sizes(cuda, gop, q_in
     416x240): every file byte-identical to the reference's, PSNR within 1e-4 dB."""
     r = _headline_run(gop, q_index, sequence, size, ds)
     assert r["diff"] == 0 and r["same"] == 3 * (gop - 1) + 2, (r["same"], r["diff"])
+    assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+
+
+@pytest.mark.skipif(not os.path.exists(_digest_path(4, 8, "layers", (1920, 1080), 1, 1)), reason="fixture not generated")
+def test_every_file_is_the_reference_s_with_other_weights(cuda):
+    """Every fixture above uses ONE set of synthetic weights (seed 0).  Here another set (seed 1), run through the real
+    reference after the arithmetic was final (tools/make_golden.py --weights_seed 1: 1080p GOP 4, q_index 8, second
+    sequence): every file byte-identical, PSNR within 1e-4 dB."""
+    r = _headline_run(4, 8, "layers", (1920, 1080), 1, weights_seed=1)
+    assert r["diff"] == 0 and r["same"] == 11, (r["same"], r["diff"])
     assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
     assert r["psnr_err"] < 1e-4
 

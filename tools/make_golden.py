@@ -154,6 +154,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ca", action="store_true", help="fixture of the real content-adaptive script's RD search")
     ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic sequence (--ca)")
+    ap.add_argument("--weights_seed", type=int, default=0, help="seed of the synthetic weights (pmctf_synth.synth_state_dict)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--width", type=int, default=128)
     ap.add_argument("--height", type=int, default=128)
@@ -192,7 +193,7 @@ def main():
     for n in (1, 2):
         t = pMCTF(num_me_stages=n).state_dict()
         json.dump({k: list(v.shape) for k, v in t.items()}, open(os.path.join(args.out, f"state_dict_keys_me{n}.json"), "w"))
-    sd = pmctf_synth.synth_state_dict(template, seed=0)
+    sd = pmctf_synth.synth_state_dict(template, seed=args.weights_seed)
     net.load_state_dict(sd, strict=True)
     net.update(force=True)
     out = {}
@@ -349,6 +350,10 @@ def main():
         suffix += "_" + args.sequence
     if args.me_downsample != 1:
         suffix += f"_ds{args.me_downsample}"
+    if args.weights_seed != 0:
+        suffix += f"_w{args.weights_seed}"
+    if args.gop_only and (args.digest or args.gop > 4):
+        suffix += "_digest"
     path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
     np.savez_compressed(path, **out)
     json.dump(meta, open(os.path.join(args.out, f"reference_{W}x{H}{suffix}.meta.json"), "w"), indent=1)
