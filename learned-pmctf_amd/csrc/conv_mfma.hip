@@ -1427,8 +1427,10 @@ __global__ __launch_bounds__(256, OCC) void conv16_band_kernel(ConvArgs a, int t
 // workgroup stages 64 channels of 16*NT pixels at a time (double-buffered, one barrier per 64 channels), every wave
 // multiplies all the pixels by its own MTW cout tiles (16*MTW*NT matrix instructions per k-chunk and wave), LDS
 // addresses are one register plus immediates.  Same sum order as everywhere: acc = bias, channels ascending.
-template <int MTW, int NT>
-__global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int tiles_total) {
+// RB: "reduce-B" (PMCTF_SUM_*: the reduction in blocks of `bchunks` 16-channel chunks, the first block's chain from the
+// bias, later blocks from zero, block results added in turn) with a second accumulator set.
+template <int MTW, int NT, bool RB = false>
+__global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int tiles_total, int bchunks) {
     constexpr int PX = 16 * NT, KC = 64, KP = KC + 2, SLOTS = PX * (KC / 4) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -1439,6 +1441,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int ti
     const int nchunk = (a.ncb + 3) >> 2;
 
     f32x4 acc[MTW][NT];
+    f32x4 tot[RB ? MTW : 1][RB ? NT : 1];
+    int left = bchunks;                                          // 16-channel chunks until the current reduction block ends
+    bool first = true;
     const float *wt[MTW];                                        // fragment base of each tile: + cb * mtp * 256 per chunk
     bool live[MTW];
 #pragma unroll
@@ -1491,6 +1496,20 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int ti
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
             if (sb < nsub) {
+                if constexpr (RB) {
+                    if (left == 0) {                              // a reduction block is complete
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                tot[i][nt] = first ? acc[i][nt] : tot[i][nt] + acc[i][nt];
+                                acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        first = false;
+                        left = bchunks;
+                    }
+                    --left;
+                }
                 {   // next 16-channel block's fragments (the last block re-reads its own: no branch)
                     const int cbn = 4 * c + sb + 1 < a.ncb ? 4 * c + sb + 1 : a.ncb - 1;
 #pragma unroll
@@ -1516,6 +1535,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(ConvArgs a, long P, int ti
         }
         if (more) stash(lds + ((c + 1) & 1) * (PX * KP));
         __syncthreads();
+    }
+    if constexpr (RB) {
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[i][nt] = tot[i][nt] + acc[i][nt];
+        }
     }
 
     PM_EPILOGUE_NOTRANS(a,
@@ -1899,8 +1926,14 @@ int launch_1x1_t(const ConvArgs &a, long P, int tiles, hipStream_t st) {
     const int gy = (tiles + WAVES * MTW - 1) / (WAVES * MTW);
     if (gx > 0x7fffffffL) return PMCTF_EINVAL;
     const size_t smem = (size_t)2 * PX * 66 * sizeof(float);
+    const SumCfg sc = t_sum;
+    if (sc.bsum) {
+        note_launch("conv1x1_kernel<MTW, NT, true>", MTW, NT, 1, dim3((unsigned)gx, gy));
+        PM_LAUNCH((conv1x1_kernel<MTW, NT, true>), dim3((unsigned)gx, gy), dim3(256), smem, st, a, P, tiles, sc.bchunks);
+        return pm_launch_status();
+    }
     note_launch("conv1x1_kernel<MTW, NT>", MTW, NT, 1, dim3((unsigned)gx, gy));
-    PM_LAUNCH((conv1x1_kernel<MTW, NT>), dim3((unsigned)gx, gy), dim3(256), smem, st, a, P, tiles);
+    PM_LAUNCH((conv1x1_kernel<MTW, NT>), dim3((unsigned)gx, gy), dim3(256), smem, st, a, P, tiles, 0);
     return pm_launch_status();
 }
 int launch_1x1(const ConvArgs &a, int tiles, hipStream_t st) {
@@ -2005,8 +2038,10 @@ extern "C" int pmctf_conv2d_nhwc_geom_opts_f32(const float *x, const float *wp, 
     hipStream_t st = (hipStream_t)stream;
     g_last_len = 0;
     g_last_launch[0] = 0;
-    if (!sc.bsum && act <= pm::ACT_LEAKY && KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
-        knob("K11") != 0 && MT * MB >= knob("K11_MIN_TILES")) {      // waves split the cout tiles: needs >= 2 tiles per wave to pay
+    if ((!sc.bsum || sc.bias_first) && act <= pm::ACT_LEAKY && KH == 1 && KW == 1 && stride == 1 && pad_top == 0 && pad_left == 0 && Ho == H && Wo == W && (Cin % CB) == 0 &&
+        knob("K11") != 0 && MT * MB >= (sc.bsum ? 4 : knob("K11_MIN_TILES"))) {      // waves split the cout tiles: needs >= 2 tiles
+        // per wave to pay against the pipelined tap kernels; a blocked reduction has only the generic kernel as the alternative
+        // (256 -> 64 on 576x960 with blocks of 96 channels: 33 -> 68 TFLOP/s)
         a.mtp = MT;
         return launch_1x1(a, MT * MB, st);
     }
