@@ -511,12 +511,13 @@ def test_gop4_960x544_vs_reference(setup):
     assert same == 11 and diff == 0, (same, diff)
 
 
-def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, weights_seed=0):
+def _digest_path(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, weights_seed=0, threads=0):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                        "reference_%dx%d_gop%d_me4%s%s%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
-                                                                          "" if sequence == "pan" else "_" + sequence,
-                                                                          "" if me_downsample == 1 else f"_ds{me_downsample}",
-                                                                          "" if weights_seed == 0 else f"_w{weights_seed}"))
+                        "reference_%dx%d_gop%d_me4%s%s%s%s%s_digest.npz" % (size[0], size[1], gop, "" if q_index == 3 else f"_q{q_index}",
+                                                                            "" if sequence == "pan" else "_" + sequence,
+                                                                            "" if me_downsample == 1 else f"_ds{me_downsample}",
+                                                                            "" if weights_seed == 0 else f"_w{weights_seed}",
+                                                                            "" if not threads else f"_t{threads}"))
 
 
 # BASELINE configs[2] (GOP 8, q_index 3) and configs[3] (GOP 16, the six points of the RD sweep {0,4,8,12,16,20}) plus the
@@ -531,16 +532,30 @@ HEADLINE_PINS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 _headline_cache = {}
 
 
-def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, precision="f32", weights_seed=0):
+def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample=1, precision="f32", weights_seed=0,
+                  threads=0):
+    """threads: the intra-op thread count of the reference run behind the digest (0: 8, as for every fixture without a _tN
+    suffix); the product follows it through PMCTF_ATEN_THREADS"""
     import hashlib
     import pmctf_gop
-    key = (gop, q_index, sequence, size, me_downsample, precision, weights_seed)
+    key = (gop, q_index, sequence, size, me_downsample, precision, weights_seed, threads)
     if key in _headline_cache:
         return _headline_cache[key]
-    g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample, weights_seed))
+    g = np.load(_digest_path(gop, q_index, sequence, size, me_downsample, weights_seed, threads))
     net, _ = product_model(4, weights_seed=weights_seed)
     net.precision = precision
-    assert net.engine().precision == precision
+    old_t = os.environ.get("PMCTF_ATEN_THREADS")
+    try:
+        if threads:
+            os.environ["PMCTF_ATEN_THREADS"] = str(threads)
+            net._engine = None
+        assert net.engine().precision == precision and (not threads or net.engine().aten_threads == threads)
+    finally:
+        if threads:
+            if old_t is None:
+                os.environ.pop("PMCTF_ATEN_THREADS", None)
+            else:
+                os.environ["PMCTF_ATEN_THREADS"] = old_t
     net.engine().keep_streams = True
     w, h = size
     if sequence == "pan":
@@ -573,7 +588,7 @@ def _headline_run(gop, q_index, sequence="pan", size=(1920, 1080), me_downsample
            "bpp": sum(enc["bits"]) / (gop * w * h), "bpp_ref": float(g["gop.bits"].sum()) / (gop * w * h)}
     print(f"{w}x{h} GOP-{gop} q_index {q_index} ({sequence}): bpp {out['bpp']:.6f} (reference {out['bpp_ref']:.6f}), max PSNR error "
           f"{out['psnr_err']:.3e} dB, {same} of {same + diff} files byte-identical, bit deltas {out['dbits']}")
-    d = os.environ.get("PMCTF_HEADLINE_REPORT") if precision == "f32" and weights_seed == 0 else None
+    d = os.environ.get("PMCTF_HEADLINE_REPORT") if precision == "f32" and weights_seed == 0 and not threads else None
     if d:       # builder's measuring run: collect what the pins file is written from
         import json
         os.makedirs(d, exist_ok=True)
@@ -751,6 +766,17 @@ def test_every_file_is_the_reference_s_with_other_weights(cuda):
     sequence): every file byte-identical, PSNR within 1e-4 dB."""
     r = _headline_run(4, 8, "layers", (1920, 1080), 1, weights_seed=1)
     assert r["diff"] == 0 and r["same"] == 11, (r["same"], r["diff"])
+    assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
+    assert r["psnr_err"] < 1e-4
+
+
+@pytest.mark.parametrize("threads", [t for t in (4, 16) if os.path.exists(_digest_path(2, 3, threads=t))])
+def test_every_file_is_the_reference_s_at_other_thread_counts(cuda, threads):
+    """The reference's own results depend on its intra-op thread count in one place — which elements of torch.sigmoid take
+    ATen's scalar tail (the convolution rules are the same for 2, 4, 8 and 16 threads: measured on the CPU); PMCTF_ATEN_THREADS
+    names it.  A 1080p pair coded by the real reference with 4 and with 16 threads: every file byte-identical."""
+    r = _headline_run(2, 3, threads=threads)
+    assert r["diff"] == 0 and r["same"] == 5, (r["same"], r["diff"])
     assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
     assert r["psnr_err"] < 1e-4
 

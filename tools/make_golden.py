@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--ca", action="store_true", help="fixture of the real content-adaptive script's RD search")
     ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic sequence (--ca)")
     ap.add_argument("--weights_seed", type=int, default=0, help="seed of the synthetic weights (pmctf_synth.synth_state_dict)")
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads for the reference run (0: 8, as for every other fixture)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--width", type=int, default=128)
     ap.add_argument("--height", type=int, default=128)
@@ -171,7 +172,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(args.threads or 8)     # 8: the thread count every fixture without a _tN suffix was generated with
     if args.ca:
         return content_adaptive_fixture(args)
     pMCTF, EntropyCoder = import_reference()
@@ -352,6 +353,8 @@ def main():
         suffix += f"_ds{args.me_downsample}"
     if args.weights_seed != 0:
         suffix += f"_w{args.weights_seed}"
+    if args.threads:
+        suffix += f"_t{args.threads}"
     if args.gop_only and (args.digest or args.gop > 4):
         suffix += "_digest"
     path = os.path.join(args.out, f"reference_{W}x{H}{suffix}.npz")
