@@ -741,7 +741,8 @@ def test_1080p_gop8_reduced_resolution_motion_vs_reference(cuda):
 _ATEN_OTHER = [c for c in ((8, 3, "layers", (1920, 1080), 1), (16, 3, "layers", (1920, 1080), 1), (8, 3, "pan", (1366, 768), 1),
                             (2, 3, "layers", (3840, 2160), 1), (8, 3, "pan", (1920, 1080), 2), (4, 3, "layers", (1280, 720), 1),
                             (4, 12, "pan", (832, 480), 1), (2, 3, "layers", (2560, 1440), 1),
-                            (4, 3, "layers", (640, 360), 1), (4, 3, "pan", (416, 240), 1))
+                            (4, 3, "layers", (640, 360), 1), (4, 3, "pan", (416, 240), 1),
+                            (8, 10, "layers", (1920, 1080), 2), (8, 16, "layers", (1366, 768), 1))
                if os.path.exists(_digest_path(c[0], c[1], c[2], c[3], c[4]))]
 
 
@@ -752,7 +753,8 @@ def test_every_file_is_the_reference_s_other_sequences_and_sizes(cuda, gop, q_in
     1366x768 (planes small enough that ATen leaves oneDNN for some layers: the "gemm" / "gemv 3x3" rules), a 3840x2160
     pair, motion at half resolution, and five configurations the summation rules were NOT fitted on, their digests
     generated from the real reference after the rules were final (1280x720, 832x480 at q 12, one 2560x1440 pair, 640x360,
-    416x240): every file byte-identical to the reference's, PSNR within 1e-4 dB."""
+    416x240, 1080p GOP 8 at q 10 with half-resolution motion, 1366x768 GOP 8 at q 16 on the second sequence): every file
+    byte-identical to the reference's, PSNR within 1e-4 dB."""
     r = _headline_run(gop, q_index, sequence, size, ds)
     assert r["diff"] == 0 and r["same"] == 3 * (gop - 1) + 2, (r["same"], r["diff"])
     assert r["bits"] == r["ref_bits"] and r["bits_mv"] == r["ref_bits_mv"]
