@@ -1242,6 +1242,11 @@ __device__ __forceinline__ void ll_ar_row2_body(const LLArgs &a, const int h, fl
     }
 }
 
+// The two halves are two instantiations (their weight streams have different lengths, and ring slots must be compile-time
+// constants): the branch below is uniform per wave (waves 0-1 / 2-3), and both bodies execute the SAME sequence of
+// s_barrier — one in the prologue, fifteen per position (two per type-B layer, one per dense layer, two around the 128 -> 2
+// head, one after the entropy decode) — every one of them outside any `if constexpr (HALF ...)`.  Keep it that way: a
+// barrier added to one half only deadlocks the workgroup.
 template <int NP>
 __global__ __launch_bounds__(2 * NF) void ll_ar_row2_kernel(LLArgs a, int h) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
